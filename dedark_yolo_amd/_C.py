@@ -1,0 +1,101 @@
+"""ctypes binding of libdedark_yolo.so (the C-ABI declared in include/dedark_yolo.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdedark_yolo.so")
+
+DY_F32, DY_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src", vp), ("src_ld", i64), ("N", i32), ("Hs", i32), ("Ws", i32), ("Cs", i32), ("w", vp), ("dst", vp),
+                ("dst_ld", i64), ("Hd", i32), ("Wd", i32), ("Cd", i32), ("KH", i32), ("KW", i32), ("stride", i32),
+                ("pad", i32), ("dil", i32), ("scale", vp), ("shift", vp), ("act", i32), ("stats", vp), ("accumulate", i32),
+                ("dtype", i32)]
+
+
+class DetMaps(C.Structure):
+    _fields_ = [("map", vp * 3), ("map_ld", i64 * 3), ("h", i32 * 3), ("w", i32 * 3), ("stride", f32 * 3), ("B", i32),
+                ("nc", i32), ("n_levels", i32), ("dtype", i32)]
+
+
+_SIGS = {
+    "dy_version": [],
+    "dy_frontend_init": [],
+    "dy_conv2d_fwd": [C.POINTER(ConvDesc), vp],
+    "dy_conv2d_dgrad": [C.POINTER(ConvDesc), vp],
+    "dy_conv2d_wgrad": [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "dy_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "dy_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "dy_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp],
+    "dy_bn_fold_eval": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
+    "dy_bn_act_fwd": [vp, i64, vp, vp, i32, vp, i64, vp, i64, i64, i32, i32, vp],
+    "dy_bn_act_bwd_reduce": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, i32, i32, vp],
+    "dy_bn_act_bwd_apply": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp],
+    "dy_maxpool_fwd": [vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "dy_maxpool_bwd": [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "dy_upsample_nearest_fwd": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+    "dy_upsample_nearest_bwd": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
+    "dy_copy2d": [vp, i64, vp, i64, i64, i32, i32, i32, vp],
+    "dy_cast": [vp, i32, vp, i32, i64, vp],
+    "dy_asff_fuse_fwd": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, i32, vp],
+    "dy_asff_fuse_bwd": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32,
+                         i32, i32, vp],
+    "dy_image_to_nhwc8": [vp, i32, i32, i32, vp, i32, i32, i32, vp],
+    "dy_resize_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "dy_filter_params_fwd": [vp, i32, vp, i32, vp],
+    "dy_filter_params_bwd": [vp, i32, vp, vp, i32, vp],
+    "dy_filters_pointwise_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "dy_filters_pointwise_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dy_usm_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dy_usm_bwd": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dy_loss_prepare_targets": [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],
+    "dy_loss_decode": [C.POINTER(DetMaps), vp, vp],
+    "dy_tal_assign": [C.POINTER(DetMaps), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],
+    "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],
+    "dy_loss_bwd": [C.POINTER(DetMaps), vp * 3, i64 * 3, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp],
+    "dy_detect_decode": [C.POINTER(DetMaps), vp, vp],
+    "dy_preprocess_batch": [vp, vp, vp, f32, i32, i32, vp, i64, vp],
+    "dy_sumsq": [vp, i64, vp, vp],
+    "dy_sgd_step": [vp, vp, vp, vp, f32, f32, f32, i32, f32, vp, f32, i64, vp],
+    "dy_adamw_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, vp, f32, i64, vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"dedark_yolo_amd: HIP library not built: {LIB_PATH} (run __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.dy_last_error.restype = C.c_char_p
+        L.dy_last_error.argtypes = []
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = sig
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ["dy_last_error"] + list(_SIGS)
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {L.dy_last_error().decode()}")

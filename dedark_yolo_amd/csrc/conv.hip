@@ -1,0 +1,650 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (CDNA4): forward, data-gradient, weight-gradient.
+//
+// Replaces nn.Conv2d as used by Conv (reference ultralytics/nn/modules/conv.py:38-55), add_conv (block.py:24-45),
+// ConvBlock (common.py:9-23), Detect heads (head.py:40-46), RFBblock (block.py:703-734), extractor Linear (common.py:65-66).
+//
+// GEMM view (forward):  D[m][n] = sum_k A[m][k] * Wp[n][k]
+//   m = (image, ho, wo) output pixel, n = output channel, k = (kh, kw, ci) with ci fastest (NHWC gather, 16-byte vectors).
+// Tile: BM x BN x (128 bytes of K) per step, 256 threads = 4 waves (WM x WN), each wave TM x TN MFMA 32x32 tiles.
+//   bf16: v_mfma_f32_32x32x16_bf16  (K step 64 elements);  f32: v_mfma_f32_32x32x2_f32 (exact f32, K step 32 elements).
+// LDS: A tile [BM][144 B], B tile [BN][144 B]  (128 B of K + 16 B pad: conflict-free ds_read_b128 / ds_write_b128).
+// Pipeline: global -> registers prefetch of step s+1 overlaps the MFMAs of step s (register staging; single LDS buffer).
+// Block ids are remapped so that each XCD (private L2) owns a contiguous range of output tiles (3x3 halo rows and the
+// weight panel stay L2-resident).
+#include "dy_common.h"
+#include "../../include/dedark_yolo.h"
+
+namespace {
+
+constexpr int ROWB = 144;       // LDS bytes per tile row
+constexpr int NTHREADS = 256;
+
+struct ConvP {
+  const char* src;
+  long src_ld;
+  int N, Hs, Ws, Cs;
+  const char* w;
+  char* dst;
+  long dst_ld;
+  int Hd, Wd, Cd;
+  int KH, KW, stride, pad, dil;
+  const float* scale;
+  const float* shift;
+  int act;
+  double* stats;
+  int accumulate;
+  long M;     // N*Hd*Wd
+  int Ktot;   // KH*KW*Cs
+  int tiles_n;
+  int nblk;
+};
+
+__device__ inline int xcd_remap(int bid, int nblk) {
+  // bijective: blocks b, b+8, ... share an XCD; give each XCD a contiguous chunk of tile ids
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+// ---- MFMA over one staged K-step. LDS rows hold 128 bytes of K. ------------------------------------------------
+template <typename T, int TM, int TN>
+__device__ inline void mma_step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    u32x4 af[TM], bfr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      af[i] = *reinterpret_cast<const u32x4*>(As + (a_row0 + i * 32 + r) * ROWB + kk * 32 + h * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bfr[j] = *reinterpret_cast<const u32x4*>(Bs + (b_row0 + j * 32 + r) * ROWB + kk * 32 + h * 16);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (sizeof(T) == 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]),
+                                                              acc[i][j], 0, 0, 0);
+        } else {
+          // lane half h holds k = kk*8 + 4h + q; A and B use the same k permutation, so the sum is exact
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, af[i][q]),
+                                                             __builtin_bit_cast(float, bfr[j][q]), acc[i][j], 0, 0, 0);
+        }
+      }
+  }
+}
+
+// ---- forward / dgrad kernel --------------------------------------------------------------------------------------
+// MODE 0: src coord = o*stride - pad + k*dil            (forward gather)
+// MODE 1: t = o + pad - k*dil ; valid iff t % stride == 0 ; src coord = t / stride   (data gradient gather)
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
+  constexpr int VE = DT<T>::VE;
+  constexpr int BK = 8 * VE;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;   // vectors per thread for A / B
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+  char* As = smem;
+  char* Bs = smem + BM * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int kv = tid & 7, r0 = tid >> 3;
+  // per-row source bases
+  const char* a_base[AR];
+  int a_h[AR], a_w[AR];
+  bool a_ok[AR];
+  const long HWd = (long)p.Hd * p.Wd;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    long m = m0 + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    long mm = a_ok[i] ? m : 0;
+    int img = (int)(mm / HWd);
+    int rem = (int)(mm - (long)img * HWd);
+    int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    a_base[i] = p.src + (long)img * p.Hs * p.Ws * p.src_ld * (long)sizeof(T);
+    if (MODE == 0) {
+      a_h[i] = oh * p.stride - p.pad;
+      a_w[i] = ow * p.stride - p.pad;
+    } else {
+      a_h[i] = oh + p.pad;
+      a_w[i] = ow + p.pad;
+    }
+  }
+  // k state of this thread's vector column: k = k0 + kv*VE -> (kh, kw, ci)
+  int kcur = kv * VE;
+  int ci, kh, kw;
+  {
+    int tap = kcur / p.Cs;
+    ci = kcur - tap * p.Cs;
+    kh = tap / p.KW;
+    kw = tap - kh * p.KW;
+  }
+  const char* b_ptr[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    int n = n0 + r0 + 32 * j;
+    b_ok[j] = n < p.Cd;
+    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.Ktot + kcur) * (long)sizeof(T);
+  }
+
+  u32x4 ra[AR], rb[BR];
+  auto load_step = [&]() {
+    const bool kvalid = kcur < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      bool ok = kvalid && a_ok[i];
+      int sh, sw;
+      if (MODE == 0) {
+        sh = a_h[i] + kh * p.dil;
+        sw = a_w[i] + kw * p.dil;
+      } else {
+        int th = a_h[i] - kh * p.dil, tw = a_w[i] - kw * p.dil;
+        ok = ok && th >= 0 && tw >= 0;
+        if (p.stride == 1) {
+          sh = th;
+          sw = tw;
+        } else {
+          sh = th / p.stride;
+          sw = tw / p.stride;
+          ok = ok && (sh * p.stride == th) && (sw * p.stride == tw);
+        }
+      }
+      ok = ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(a_base[i] + (((long)sh * p.Ws + sw) * p.src_ld + ci) * (long)sizeof(T));
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kvalid && b_ok[j]) v = *reinterpret_cast<const u32x4*>(b_ptr[j]);
+      rb[j] = v;
+    }
+  };
+  auto advance = [&]() {
+    kcur += BK;
+    ci += BK;
+    while (ci >= p.Cs) {
+      ci -= p.Cs;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) b_ptr[j] += BK * sizeof(T);
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * ROWB + kv * 16) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * j) * ROWB + kv * 16) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (p.Ktot + BK - 1) / BK;
+  load_step();
+  store_step();
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) {
+      advance();
+      load_step();
+    }
+    mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
+    __syncthreads();
+    if (more) {
+      store_step();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int cl = lane & 31, hh = lane >> 5;
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  T* dst = reinterpret_cast<T*>(p.dst);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + cl;
+    const bool nok = n < p.Cd;
+    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+    const float sf = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (nok && m < p.M) {
+          float a = acc[i][j][r];
+          csum[j] += a;
+          csq[j] += a * a;
+          float v = dy_act(p.act, a * sc + sf);
+          T* o = dst + m * p.dst_ld + n;
+          if (p.accumulate) v += DT<T>::ld(o);
+          DT<T>::st(o, v);
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();                         // smem reuse
+    float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (hh == 0) {
+        int c = wn * (BN / WN) + j * 32 + cl;
+        red[(wm * BN + c) * 2] = s1;
+        red[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int n = n0 + tid;
+      if (n < p.Cd) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += red[(w * BN + tid) * 2];
+          s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        atomic_add_f64(p.stats + n, (double)s1);
+        atomic_add_f64(p.stats + p.Cd + n, (double)s2);
+      }
+    }
+  }
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+// dW[co][k] += sum_m dz[m][co] * X[m][k],  k = (kh,kw,ci).  GEMM rows = co, cols = k, reduction over pixels m.
+// Both operands are pixel-major in HBM, MFMA wants the reduction index contiguous per lane: each thread loads a
+// VE x VE (pixels x channels) block with 16-byte loads, transposes it in registers and writes pixel-contiguous
+// 16-byte rows to LDS.  Grid = (co tiles * k tiles, pixel splits); partial tiles are added with f32 atomics
+// (32 consecutive floats per half-wave = the full-rate atomic shape).
+struct WgP {
+  const char* x;
+  long x_ld;
+  int N, Hi, Wi, Cin;
+  const char* dz;
+  long dz_ld;
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad, dil;
+  float* dw;
+  long M;
+  int Ktot;
+  int tiles_k;
+  long chunk;    // pixels per split (multiple of MK)
+  int pointwise;
+};
+
+template <typename T, int VE> struct Transposer;
+template <> struct Transposer<float, 4> {
+  // in[e] = 4 channels of pixel e ; out[c] = 4 pixels of channel c
+  __device__ static inline void run(const u32x4 (&in)[4], u32x4 (&out)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4 o = {in[0][c], in[1][c], in[2][c], in[3][c]};
+      out[c] = o;
+    }
+  }
+};
+template <> struct Transposer<bf16_t, 8> {
+  // in[e] = 8 bf16 channels (4 dwords) of pixel e ; out[c] = 8 pixels of channel c
+  __device__ static inline void run(const u32x4 (&in)[8], u32x4 (&out)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t lo = in[2 * q][c >> 1], hi = in[2 * q + 1][c >> 1];
+        // select half (c&1) of lo into bits 0-15 and of hi into bits 16-31
+        o[q] = (c & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
+      out[c] = o;
+    }
+  }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgP p) {
+  constexpr int VE = DT<T>::VE;
+  constexpr int MK = 8 * VE;                 // pixels per step
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NA = 8 * (BM / VE), NB = 8 * (BN / VE);    // VE x VE units in the A (dz) / B (x) tiles
+  constexpr int UPT = (NA + NB + NTHREADS - 1) / NTHREADS;
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+  char* As = smem;
+  char* Bs = smem + BM * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_c = blockIdx.x / p.tiles_k, tile_k = blockIdx.x % p.tiles_k;
+  const int c0 = tile_c * BM, k0 = tile_k * BN;
+  const long m_begin = (long)blockIdx.y * p.chunk;
+  const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+  if (m_begin >= m_end) return;
+
+  // static unit assignment
+  bool u_isA[UPT], u_on[UPT], u_chan_ok[UPT];
+  int u_pg[UPT], u_cg[UPT];       // pixel group (0..7), channel group
+  int u_kh[UPT], u_kw[UPT], u_ci[UPT];
+#pragma unroll
+  for (int q = 0; q < UPT; ++q) {
+    int u = tid + q * NTHREADS;
+    u_on[q] = u < NA + NB;
+    u_isA[q] = u < NA;
+    u_kh[q] = u_kw[q] = u_ci[q] = 0;
+    if (u_isA[q]) {
+      u_cg[q] = u % (BM / VE);
+      u_pg[q] = u / (BM / VE);
+      u_chan_ok[q] = (c0 + u_cg[q] * VE) < p.Cout;
+    } else {
+      int v = u - NA;
+      u_cg[q] = v % (BN / VE);
+      u_pg[q] = (v / (BN / VE)) & 7;
+      int k = k0 + u_cg[q] * VE;
+      u_chan_ok[q] = k < p.Ktot;
+      int kk = u_chan_ok[q] ? k : 0;
+      int tap = kk / p.Cin;
+      u_ci[q] = kk - tap * p.Cin;
+      u_kh[q] = tap / p.KW;
+      u_kw[q] = tap - u_kh[q] * p.KW;
+    }
+  }
+  const long HWo = (long)p.Ho * p.Wo;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 reg[UPT][VE];
+  auto load_step = [&](long mbase) {
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const long mfirst = mbase + u_pg[q] * VE;
+      if (u_isA[q]) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          long m = mfirst + e;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (u_on[q] && u_chan_ok[q] && m < m_end)
+            v = *reinterpret_cast<const u32x4*>(p.dz + (m * p.dz_ld + c0 + u_cg[q] * VE) * (long)sizeof(T));
+          reg[q][e] = v;
+        }
+      } else if (p.pointwise) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          long m = mfirst + e;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (u_on[q] && u_chan_ok[q] && m < m_end)
+            v = *reinterpret_cast<const u32x4*>(p.x + (m * p.x_ld + u_ci[q]) * (long)sizeof(T));
+          reg[q][e] = v;
+        }
+      } else {
+        long mm = mfirst < p.M ? mfirst : 0;
+        int img = (int)(mm / HWo);
+        int rem = (int)(mm - (long)img * HWo);
+        int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          long m = mfirst + e;
+          int ih = oh * p.stride - p.pad + u_kh[q] * p.dil;
+          int iw = ow * p.stride - p.pad + u_kw[q] * p.dil;
+          bool ok = u_on[q] && u_chan_ok[q] && m < m_end && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (ok)
+            v = *reinterpret_cast<const u32x4*>(p.x + ((((long)img * p.Hi + ih) * p.Wi + iw) * p.x_ld + u_ci[q]) * (long)sizeof(T));
+          reg[q][e] = v;
+          if (++ow == p.Wo) {
+            ow = 0;
+            if (++oh == p.Ho) { oh = 0; ++img; }
+          }
+        }
+      }
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      if (!u_on[q]) continue;
+      u32x4 t[VE];
+      Transposer<T, VE>::run(reg[q], t);
+      char* base = (u_isA[q] ? As : Bs) + (u_cg[q] * VE) * ROWB + u_pg[q] * 16;
+#pragma unroll
+      for (int c = 0; c < VE; ++c) *reinterpret_cast<u32x4*>(base + c * ROWB) = t[c];
+    }
+  };
+
+  load_step(m_begin);
+  store_step();
+  __syncthreads();
+  for (long mb = m_begin; mb < m_end; mb += MK) {
+    const bool more = mb + MK < m_end;
+    if (more) load_step(mb + MK);
+    mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
+    __syncthreads();
+    if (more) {
+      store_step();
+      __syncthreads();
+    }
+  }
+  const int cl = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int k = k0 + wn * (BN / WN) + j * 32 + cl;
+    if (k >= p.Ktot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = c0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (co < p.Cout) atomic_add_f32(p.dw + (long)co * p.Ktot + k, acc[i][j][r]);
+      }
+  }
+}
+
+// ---- weight (un)packing -----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cout_pad, int Cin,
+                                   int Cin_pad, int KH, int KW, int transposed) {
+  long total = (long)Cout_pad * KH * KW * Cin_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int co, kh, kw, ci;
+    long r = i;
+    if (!transposed) {       // [Cout_pad][KH][KW][Cin_pad]
+      ci = (int)(r % Cin_pad); r /= Cin_pad;
+      kw = (int)(r % KW); r /= KW;
+      kh = (int)(r % KH); r /= KH;
+      co = (int)r;
+    } else {                 // [Cin_pad][KH][KW][Cout_pad]
+      co = (int)(r % Cout_pad); r /= Cout_pad;
+      kw = (int)(r % KW); r /= KW;
+      kh = (int)(r % KH); r /= KH;
+      ci = (int)r;
+    }
+    float v = (ci < Cin && co < Cout) ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+    DT<T>::st(out + i, v);
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cout, int Cin, int Cin_pad,
+                                    int KH, int KW) {
+  long total = (long)Cout * Cin * KH * KW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    int kw = (int)(r % KW); r /= KW;
+    int kh = (int)(r % KH); r /= KH;
+    int ci = (int)(r % Cin); r /= Cin;
+    int co = (int)r;
+    g[i] = dwp[(((long)co * KH + kh) * KW + kw) * Cin_pad + ci];
+  }
+}
+
+template <typename T, int MODE>
+int launch_conv(const dy_conv_desc* d, hipStream_t st) {
+  ConvP p;
+  p.src = (const char*)d->src; p.src_ld = d->src_ld; p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
+  p.w = (const char*)d->w; p.dst = (char*)d->dst; p.dst_ld = d->dst_ld; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
+  p.M = (long)d->N * d->Hd * d->Wd;
+  p.Ktot = d->KH * d->KW * d->Cs;
+  constexpr int BM = 128;
+  const int tiles_m = dy_cdiv(p.M, BM);
+  if (d->Cd <= 32) {
+    p.tiles_n = dy_cdiv(d->Cd, 32);
+    p.nblk = tiles_m * p.tiles_n;
+    conv_igemm_kernel<T, BM, 32, 4, 1, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
+  } else if (d->Cd <= 64) {
+    p.tiles_n = dy_cdiv(d->Cd, 64);
+    p.nblk = tiles_m * p.tiles_n;
+    conv_igemm_kernel<T, BM, 64, 2, 2, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
+  } else {
+    p.tiles_n = dy_cdiv(d->Cd, 128);
+    p.nblk = tiles_m * p.tiles_n;
+    conv_igemm_kernel<T, BM, 128, 2, 2, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
+  }
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+int check_conv(const dy_conv_desc* d, const char* who) {
+  DY_CHECK(d && d->src && d->w && d->dst, "%s: null pointer", who);
+  DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16, "%s: bad dtype %d", who, d->dtype);
+  const int ve = d->dtype == DY_F32 ? 4 : 8, es = d->dtype == DY_F32 ? 4 : 2;
+  DY_CHECK(d->Cs > 0 && d->Cs % ve == 0, "%s: Cs=%d must be a positive multiple of %d", who, d->Cs, ve);
+  DY_CHECK(d->src_ld >= d->Cs && (d->src_ld * es) % 16 == 0, "%s: src_ld=%ld not 16-byte aligned", who, (long)d->src_ld);
+  DY_CHECK(((uintptr_t)d->src) % 16 == 0 && ((uintptr_t)d->w) % 16 == 0, "%s: src/w pointer not 16-byte aligned", who);
+  DY_CHECK(d->dst_ld >= d->Cd && d->Cd > 0, "%s: dst_ld=%ld < Cd=%d", who, (long)d->dst_ld, d->Cd);
+  DY_CHECK(d->N > 0 && d->Hs > 0 && d->Ws > 0 && d->Hd > 0 && d->Wd > 0, "%s: empty geometry", who);
+  DY_CHECK(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "%s: bad window", who);
+  DY_CHECK(d->act >= 0 && d->act <= 2, "%s: bad act", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
+  if (int e = check_conv(d, "dy_conv2d_fwd")) return e;
+  const int ho = (d->Hs + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int wo = (d->Ws + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : launch_conv<bf16_t, 0>(d, st);
+}
+
+extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
+  if (int e = check_conv(d, "dy_conv2d_dgrad")) return e;
+  // src = dz (conv output geometry), dst = dx (conv input geometry)
+  const int ho = (d->Hd + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int wo = (d->Wd + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  DY_CHECK(ho == d->Hs && wo == d->Ws, "dy_conv2d_dgrad: dz %dx%d does not match conv output %dx%d", d->Hs, d->Ws, ho, wo);
+  DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : launch_conv<bf16_t, 1>(d, st);
+}
+
+namespace {
+template <typename T>
+int launch_wgrad(WgP p, hipStream_t st) {
+  constexpr int MK = 8 * DT<T>::VE;
+  int bm, bn;
+  bn = p.Ktot <= 32 ? 32 : (p.Ktot <= 64 ? 64 : 128);
+  if (bn == 32) bm = 128;
+  else if (bn == 64) bm = p.Cout <= 64 ? 64 : 128;
+  else bm = p.Cout <= 32 ? 32 : (p.Cout <= 64 ? 64 : 128);
+  const int tiles_c = dy_cdiv(p.Cout, bm);
+  p.tiles_k = dy_cdiv(p.Ktot, bn);
+  const int tiles = tiles_c * p.tiles_k;
+  // enough splits to fill the chip (~4 blocks per CU), at least 4 steps of pixels per split
+  long max_splits = (p.M + 4 * MK - 1) / (4 * MK);
+  long want = (1024 + tiles - 1) / tiles;
+  long splits = want < max_splits ? want : max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  long chunk = (p.M + splits - 1) / splits;
+  chunk = (chunk + MK - 1) / MK * MK;
+  splits = (p.M + chunk - 1) / chunk;
+  p.chunk = chunk;
+  dim3 grid(tiles, (unsigned)splits);
+#define WG(BM_, BN_, WM_, WN_) conv_wgrad_kernel<T, BM_, BN_, WM_, WN_><<<grid, NTHREADS, 0, st>>>(p)
+  if (bm == 128 && bn == 128) WG(128, 128, 2, 2);
+  else if (bm == 64 && bn == 128) WG(64, 128, 1, 4);
+  else if (bm == 32 && bn == 128) WG(32, 128, 1, 4);
+  else if (bm == 128 && bn == 64) WG(128, 64, 4, 1);
+  else if (bm == 64 && bn == 64) WG(64, 64, 2, 2);
+  else WG(128, 32, 4, 1);
+#undef WG
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin, const void* dz, int64_t dz_ld,
+                               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int dil, float* dw, int dtype,
+                               void* stream) {
+  DY_CHECK(x && dz && dw, "dy_conv2d_wgrad: null pointer");
+  DY_CHECK(dtype == DY_F32 || dtype == DY_BF16, "dy_conv2d_wgrad: bad dtype");
+  const int ve = dtype == DY_F32 ? 4 : 8, es = dtype == DY_F32 ? 4 : 2;
+  DY_CHECK(Cin % ve == 0 && Cout % ve == 0, "dy_conv2d_wgrad: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, ve);
+  DY_CHECK((x_ld * es) % 16 == 0 && (dz_ld * es) % 16 == 0, "dy_conv2d_wgrad: ld not 16-byte aligned");
+  DY_CHECK(((uintptr_t)x) % 16 == 0 && ((uintptr_t)dz) % 16 == 0, "dy_conv2d_wgrad: pointer not 16-byte aligned");
+  const int ho = (Hi + 2 * pad - dil * (KH - 1) - 1) / stride + 1, wo = (Wi + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  DY_CHECK(ho == Ho && wo == Wo, "dy_conv2d_wgrad: dz %dx%d does not match conv output %dx%d", Ho, Wo, ho, wo);
+  WgP p;
+  p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin;
+  p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil; p.dw = dw;
+  p.M = (long)N * Ho * Wo;
+  p.Ktot = KH * KW * Cin;
+  p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == DY_F32 ? launch_wgrad<float>(p, st) : launch_wgrad<bf16_t>(p, st);
+}
+
+extern "C" int dy_pack_weight(const float* w, void* packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int KH, int KW,
+                              int transposed, int dtype, void* stream) {
+  DY_CHECK(w && packed && Cin_pad >= Cin && Cout_pad >= Cout, "dy_pack_weight: bad args");
+  long total = (long)Cout_pad * KH * KW * Cin_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DY_F32) pack_weight_kernel<float><<<blocks, 256, 0, st>>>(w, (float*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
+  else pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, (bf16_t*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dy_unpack_wgrad(const float* dwp, float* g, int Cout, int Cin, int Cin_pad, int KH, int KW, void* stream) {
+  DY_CHECK(dwp && g, "dy_unpack_wgrad: null");
+  long total = (long)Cout * Cin * KH * KW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  unpack_wgrad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dwp, g, Cout, Cin, Cin_pad, KH, KW);
+  DY_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,137 @@
+// Common device/host helpers for the Dedark-YOLO gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define DY_F32 0
+#define DY_BF16 1
+
+#define DY_ACT_NONE 0
+#define DY_ACT_SILU 1
+#define DY_ACT_LEAKY 2   // LeakyReLU(0.1)
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ---- error plumbing (C-ABI returns int, message via dy_last_error) -------------------------------------------
+extern "C" const char* dy_last_error(void);
+void dy_set_error(const char* fmt, ...);
+
+#define DY_CHECK(cond, ...)                      \
+  do {                                           \
+    if (!(cond)) {                               \
+      dy_set_error(__VA_ARGS__);                 \
+      return 1;                                  \
+    }                                            \
+  } while (0)
+
+#define DY_LAUNCH_CHECK()                                                    \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      dy_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+
+static inline int dy_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 --------------------------------------------------------------------------------------------
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+  union { uint32_t u; float f; } c;
+  c.u = ((uint32_t)v) << 16;
+  return c.f;
+}
+__device__ inline bf16_t f32_to_bf16(float f) {
+  // plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950); round-to-nearest-even
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int id = DY_F32;
+  static constexpr int VE = 4;   // elements per 16-byte vector
+  __device__ static inline float ld(const float* p) { return *p; }
+  __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int id = DY_BF16;
+  static constexpr int VE = 8;
+  __device__ static inline float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static inline void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector load/store of VE elements into/out of float registers
+template <typename T> __device__ inline void ldvec(const T* p, float* out);
+template <> __device__ inline void ldvec<float>(const float* p, float* out) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+template <> __device__ inline void ldvec<bf16_t>(const bf16_t* p, float* out) {
+  u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    out[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ inline void stvec(T* p, const float* in);
+template <> __device__ inline void stvec<float>(float* p, const float* in) {
+  f32x4 v = {in[0], in[1], in[2], in[3]};
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ inline void stvec<bf16_t>(bf16_t* p, const float* in) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = v;
+}
+
+// ---- activations ---------------------------------------------------------------------------------------------
+__host__ __device__ inline float dy_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__host__ __device__ inline float dy_act(int act, float u) {
+  if (act == DY_ACT_SILU) return u * dy_sigmoid(u);
+  if (act == DY_ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+  return u;
+}
+// d act(u) / du
+__host__ __device__ inline float dy_dact(int act, float u) {
+  if (act == DY_ACT_SILU) {
+    float s = dy_sigmoid(u);
+    return s * (1.0f + u * (1.0f - s));
+  }
+  if (act == DY_ACT_LEAKY) return u > 0.f ? 1.0f : 0.1f;
+  return 1.0f;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of up to 1024 threads; result valid in every thread. `sm` must hold >= 17 floats.
+__device__ inline float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sm[i];
+  return r;
+}
+
+__device__ inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ inline void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

@@ -1,0 +1,443 @@
+"""Host-side operator layer: tensors -> C-ABI calls (libdedark_yolo.so).  PyTorch is plumbing only (device memory, streams).
+
+Tensor convention between modules: logical shape [B, C, H, W] (the reference's module interface), physical layout NHWC
+(`channels_last`), dtype = compute dtype (fp32 parity path or bf16 throughput path).  A channel slice of a wider buffer is a
+legal input/output ("view" = pointer + pixel stride), which is how C2f / SPPF / Detect concats cost nothing.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+from ._C import ACT_LEAKY, ACT_NONE, ACT_SILU, ConvDesc, DetMaps, call
+
+_compute_dtype = torch.float32
+_weights_epoch = 0          # bumped by the fused optimizer (it writes parameters through raw pointers)
+
+
+def set_compute_dtype(dt):
+    global _compute_dtype
+    assert dt in (torch.float32, torch.bfloat16)
+    _compute_dtype = dt
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def dt_id(dtype):
+    if dtype == torch.float32:
+        return _C.DY_F32
+    if dtype == torch.bfloat16:
+        return _C.DY_BF16
+    raise RuntimeError(f"dedark_yolo_amd: unsupported dtype {dtype}")
+
+
+def vec_elems(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def round_up(c, m):
+    return (c + m - 1) // m * m
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("dedark_yolo_amd: the HIP path needs tensors on the GPU (there is no CPU fallback)")
+
+
+def empty_nhwc(B, C_, H, W, dtype, device):
+    return torch.empty((B, C_, H, W), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def zeros_nhwc(B, C_, H, W, dtype, device):
+    return torch.zeros((B, H, W, C_), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def ld_of(t):
+    """Pixel stride (elements) of an NHWC view [B,C,H,W]; raises if `t` is not such a view."""
+    B, Cc, H, W = t.shape
+    if Cc > 1 and t.stride(1) != 1:
+        raise RuntimeError(f"dedark_yolo_amd: expected an NHWC (channels_last) view, got strides {t.stride()} for {tuple(t.shape)}")
+    ld = None
+    if W > 1:
+        ld = t.stride(3)
+    elif H > 1:
+        ld = t.stride(2)
+    elif B > 1:
+        ld = t.stride(0)
+    else:
+        ld = Cc
+    ok = ld >= Cc and (W == 1 or t.stride(3) == ld) and (H == 1 or t.stride(2) == W * ld) and (B == 1 or t.stride(0) == H * W * ld)
+    if not ok:
+        raise RuntimeError(f"dedark_yolo_amd: not a dense NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def is_nhwc_view(t):
+    try:
+        ld_of(t)
+        return True
+    except RuntimeError:
+        return False
+
+
+def as_nhwc(t, dtype=None):
+    """Boundary adapter: any [B,C,H,W] tensor -> NHWC view in `dtype` (torch relayout only when the caller hands NCHW)."""
+    dtype = dtype or _compute_dtype
+    require_gpu(t)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    ve = vec_elems(dtype)
+    if is_nhwc_view(t) and (ld_of(t) >= round_up(t.shape[1], ve)) and (ld_of(t) * t.element_size()) % 16 == 0 \
+            and t.data_ptr() % 16 == 0:
+        return t          # (a narrower-than-ld view is one of our own zero-padded buffers)
+    Cc = t.shape[1]
+    Cp = round_up(Cc, ve)
+    if Cp == Cc:
+        return t.contiguous(memory_format=torch.channels_last)
+    buf = torch.zeros((t.shape[0], t.shape[2], t.shape[3], Cp), dtype=dtype, device=t.device)
+    buf[..., :Cc] = t.permute(0, 2, 3, 1)
+    return buf.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def padded_channels(t):
+    """Channels physically readable behind view `t` when C is not a vector multiple (pad lanes must be zero)."""
+    ve = vec_elems(t.dtype)
+    Cp = round_up(t.shape[1], ve)
+    if Cp != t.shape[1] and ld_of(t) < Cp:
+        raise RuntimeError("dedark_yolo_amd: channel count needs zero padding to a 16-byte multiple")
+    return Cp
+
+
+# ------------------------------------------------------------------------------------------------ scratch arena
+class _Arena:
+    """Zero-initialised double scratch for per-channel statistics; one fill per step instead of one per conv."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+
+    def alloc(self, n, device):
+        n = round_up(n, 2)
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            cap = max(1 << 18, 4 * n)
+            self.buf = torch.zeros(cap, dtype=torch.float64, device=device)
+            self.off = 0
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+    def reset(self):
+        if self.buf is not None and self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+
+arena = _Arena()
+
+
+# ------------------------------------------------------------------------------------------------ weights
+def _pack(weight, cout_pad, cin_pad, transposed, dtype):
+    key = (cout_pad, cin_pad, transposed, dtype)
+    cache = weight.__dict__.setdefault("_dy_pack", {})
+    hit = cache.get(key)
+    tag = (_weights_epoch, weight._version)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    Co, Ci, KH, KW = weight.shape
+    out = hit[1] if hit is not None else torch.empty(cout_pad * KH * KW * cin_pad, dtype=dtype, device=weight.device)
+    w32 = weight.detach()
+    if w32.dtype != torch.float32 or not w32.is_contiguous():
+        w32 = w32.float().contiguous()
+    call("dy_pack_weight", ptr(w32), ptr(out), Co, cout_pad, Ci, cin_pad, KH, KW, 1 if transposed else 0, dt_id(dtype), stream())
+    cache[key] = (tag, out)
+    return out
+
+
+def _padded_vec(v, n):
+    """f32 per-channel vector zero-padded to n (bias for padded output channels)."""
+    if v is None:
+        return None
+    v = v.detach()
+    if v.numel() == n and v.dtype == torch.float32:
+        return v
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv + bn + act
+class ConvCtx:
+    __slots__ = ("x", "z", "aff", "weight", "bias", "bn", "act", "k", "stride", "pad", "dil", "cout", "cout_pad", "cin_pad",
+                 "has_bn", "y", "owner")
+
+
+def _conv_desc(src, w, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, KH, KW, stride, pad, dil, scale, shift, act, stats, accumulate, dtype):
+    d = ConvDesc()
+    d.src, d.src_ld = src.data_ptr(), ld_of(src)
+    d.N, d.Hs, d.Ws, d.Cs = N, Hs, Ws, Cs
+    d.w = w.data_ptr()
+    d.dst, d.dst_ld = dst.data_ptr(), ld_of(dst)
+    d.Hd, d.Wd, d.Cd = Hd, Wd, Cd
+    d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
+    d.scale, d.shift = ptr(scale), ptr(shift)
+    d.act = act
+    d.stats = ptr(stats)
+    d.accumulate = 1 if accumulate else 0
+    d.dtype = dt_id(dtype)
+    return d
+
+
+_bn_pending = {}
+
+
+def flush_bn_counters():
+    """num_batches_tracked is bumped lazily (one tiny kernel per BN per step would be pure launch overhead)."""
+    for bn, n in _bn_pending.items():
+        bn.num_batches_tracked += n
+    _bn_pending.clear()
+
+
+def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pad=0, dil=1, training=False, out=None,
+                 residual=None, owner=None):
+    """y = act(bn(conv(x) [+ bias])) [+ residual].  x: NHWC view; returns an NHWC view (into `out` when given).
+
+    Training + bn: conv kernel (raw z + batch statistics) -> finalize -> fused affine/activation/residual pass.
+    Otherwise one kernel with the affine (+bias / folded BN) and activation in the epilogue.
+    A context is pushed on `tape` when it is not None.
+    """
+    dtype = x.dtype
+    B, Cin, H, W = x.shape
+    Cout, Cw, KH, KW = weight.shape
+    if Cw != Cin:
+        raise RuntimeError(f"conv: weight expects {Cw} input channels, got {Cin}")
+    ve = vec_elems(dtype)
+    cin_pad = padded_channels(x)
+    cout_pad = round_up(Cout, ve)
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    wp = _pack(weight, cout_pad, cin_pad, False, dtype)
+    dev = x.device
+    has_bn = bn is not None
+    batch_stats = has_bn and training
+    ctx = None
+    if tape is not None:
+        ctx = ConvCtx()
+        ctx.x, ctx.weight, ctx.bias, ctx.bn, ctx.act = x, weight, bias, bn, act
+        ctx.owner = owner if owner is not None else weight
+        ctx.k, ctx.stride, ctx.pad, ctx.dil = (KH, KW), stride, pad, dil
+        ctx.cout, ctx.cout_pad, ctx.cin_pad, ctx.has_bn = Cout, cout_pad, cin_pad, has_bn
+    if batch_stats:
+        z = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+        stats = arena.alloc(2 * cout_pad, dev)
+        d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
+                       False, dtype)
+        call("dy_conv2d_fwd", C.byref(d), stream())
+        aff = torch.empty((4, cout_pad), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
+        call("dy_bn_finalize", ptr(stats), B * Ho * Wo, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+             ptr(bn.running_var), float(bn.momentum), float(bn.eps), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
+             cout_pad, stream())
+        _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
+        y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+        call("dy_bn_act_fwd", ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), act, ptr(residual),
+             ld_of(residual) if residual is not None else 0, ptr(y), ld_of(y), B * Ho * Wo, cout_pad, dt_id(dtype), stream())
+        if ctx is not None:
+            ctx.z, ctx.aff, ctx.y = z, aff, None
+    else:
+        if has_bn:                      # eval: fold running statistics
+            aff = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
+            call("dy_bn_fold_eval", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps),
+                 ptr(aff[0]), ptr(aff[1]), cout_pad, stream())
+            scale, shift = aff[0], aff[1]
+        else:
+            scale, shift = None, _padded_vec(bias, cout_pad)
+        direct = residual is None
+        y = out if (out is not None and direct) else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+        d = _conv_desc(x, wp, y, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, scale, shift, act, None, False,
+                       dtype)
+        call("dy_conv2d_fwd", C.byref(d), stream())
+        if not direct:                  # eval-time residual: y_out = y + residual
+            tgt = out if out is not None else y
+            if tgt is not y:
+                call("dy_copy2d", ptr(y), ld_of(y), ptr(tgt), ld_of(tgt), B * Ho * Wo, cout_pad, 0, dt_id(dtype), stream())
+            call("dy_copy2d", ptr(residual), ld_of(residual), ptr(tgt), ld_of(tgt), B * Ho * Wo, cout_pad, 1, dt_id(dtype),
+                 stream())
+            y = tgt
+        if ctx is not None:
+            if has_bn:
+                raise RuntimeError("conv: gradients through an eval-mode BatchNorm are not supported")
+            ctx.z, ctx.aff, ctx.y = None, None, y
+    if tape is not None:
+        tape.push(ctx)
+    return y if cout_pad == Cout else y[:, :Cout]
+
+
+def _add_pgrad(tape, p, g):
+    if p is None or not p.requires_grad:
+        return
+    if p in tape.pgrads:
+        tape.pgrads[p] = tape.pgrads[p] + g
+    else:
+        tape.pgrads[p] = g
+
+
+def _grad_dst(p):
+    """p.grad storage when the trainer enabled direct gradient placement (kernels write there; autograd gets None)."""
+    if p is not None and p.requires_grad and getattr(p, "_dy_direct", False) and p.grad is not None:
+        return p.grad
+    return None
+
+
+def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
+    """Backward of the matching conv_forward (pops its context). dy: NHWC view of the gradient wrt the conv's output
+    (for a residual conv the caller routes dy to the residual branch itself). Returns dx (NHWC view) or None."""
+    ctx = tape.pop()
+    x = ctx.x
+    dtype = x.dtype
+    dev = x.device
+    B, Cin, H, W = x.shape
+    KH, KW = ctx.k
+    Cout, cout_pad, cin_pad = ctx.cout, ctx.cout_pad, ctx.cin_pad
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    if cout_pad != Cout:
+        if padded_channels(dy) != cout_pad:
+            raise RuntimeError("conv_backward: gradient view lacks zero padding")
+    pixels = B * Ho * Wo
+    did = dt_id(dtype)
+    st = stream()
+    if ctx.has_bn:
+        aff, z, bn = ctx.aff, ctx.z, ctx.bn
+        sums = arena.alloc(2 * cout_pad, dev)
+        call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
+             ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
+        dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+        gw_, gb_ = _grad_dst(bn.weight), _grad_dst(bn.bias)
+        direct = gw_ is not None and gb_ is not None
+        if not direct:
+            dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
+            gw_, gb_ = dgb[0], dgb[1]
+        call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
+             ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
+        if not direct:
+            _add_pgrad(tape, bn.weight, gw_)
+            _add_pgrad(tape, bn.bias, gb_)
+    else:
+        y = ctx.y
+        need_bias = ctx.bias is not None and ctx.bias.requires_grad
+        if ctx.act == ACT_NONE and not need_bias:
+            dz = dy
+        else:
+            sums = arena.alloc(2 * cout_pad, dev)
+            call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(y), ld_of(y), None, None, None, None, ctx.act, 0, ptr(sums),
+                 pixels, cout_pad, did, st)
+            gb_ = _grad_dst(ctx.bias) if (need_bias and cout_pad == Cout) else None
+            db = gb_ if gb_ is not None else torch.empty(cout_pad, dtype=torch.float32, device=dev)
+            if ctx.act == ACT_NONE:
+                dz = dy
+                call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(y), ld_of(y), None, None, None, None, None, ctx.act, 0,
+                     ptr(sums), ptr(dy), ld_of(dy), None, ptr(db), 0, cout_pad, did, st)      # 0 pixels: only dbias
+            else:
+                dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+                call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(y), ld_of(y), None, None, None, None, None, ctx.act, 0,
+                     ptr(sums), ptr(dz), ld_of(dz), None, ptr(db), pixels, cout_pad, did, st)
+            if need_bias and gb_ is None:
+                gd = _grad_dst(ctx.bias)
+                if gd is not None:
+                    gd.copy_(db[:Cout])
+                else:
+                    _add_pgrad(tape, ctx.bias, db[:Cout])
+    # weight gradient
+    if ctx.owner.requires_grad:
+        dwp = torch.zeros(cout_pad * KH * KW * cin_pad, dtype=torch.float32, device=dev)
+        call("dy_conv2d_wgrad", ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride,
+             ctx.pad, ctx.dil, ptr(dwp), did, st)
+        gd = _grad_dst(ctx.owner)
+        gw = gd if gd is not None else torch.empty(ctx.weight.shape, dtype=torch.float32, device=dev)
+        call("dy_unpack_wgrad", ptr(dwp), ptr(gw), Cout, Cin, cin_pad, KH, KW, st)
+        if gd is None:
+            _add_pgrad(tape, ctx.owner, gw.view(ctx.owner.shape))
+    if not need_dx:
+        return None
+    wt = _pack(ctx.weight, cout_pad, cin_pad, True, dtype)
+    if dx_out is None:
+        dxb = empty_nhwc(B, cin_pad, H, W, dtype, dev)
+        accumulate = False
+    else:
+        dxb = dx_out
+        if padded_channels(dxb) != cin_pad:
+            raise RuntimeError("conv_backward: dx_out view too narrow")
+    d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
+                   None, accumulate, dtype)
+    call("dy_conv2d_dgrad", C.byref(d), st)
+    if dx_out is not None:
+        return dx_out
+    return dxb if cin_pad == Cin else dxb[:, :Cin]
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+def copy2d(src, dst, accumulate=False):
+    B, Cc, H, W = src.shape
+    Cp = padded_channels(src)
+    call("dy_copy2d", ptr(src), ld_of(src), ptr(dst), ld_of(dst), B * H * W, Cp, 1 if accumulate else 0, dt_id(src.dtype), stream())
+
+
+def maxpool_fwd(x, k, stride, pad, out=None, want_arg=True):
+    B, Cc, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = out if out is not None else empty_nhwc(B, Cc, Ho, Wo, x.dtype, x.device)
+    arg = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device) if want_arg else None
+    call("dy_maxpool_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), ptr(arg), B, H, W, Cc, k, stride, pad, Ho, Wo, dt_id(x.dtype),
+         stream())
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape, k, stride, pad, dx_out=None, accumulate=False):
+    B, Cc, H, W = in_shape
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    dx = dx_out if dx_out is not None else empty_nhwc(B, Cc, H, W, dy.dtype, dy.device)
+    call("dy_maxpool_bwd", ptr(dy), ld_of(dy), ptr(arg), ptr(dx), ld_of(dx), B, H, W, Cc, k, stride, pad, Ho, Wo,
+         1 if (accumulate and dx_out is not None) else 0, dt_id(dy.dtype), stream())
+    return dx
+
+
+def upsample_fwd(x, scale, out=None):
+    B, Cc, H, W = x.shape
+    y = out if out is not None else empty_nhwc(B, Cc, H * scale, W * scale, x.dtype, x.device)
+    call("dy_upsample_nearest_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), B, H, W, Cc, scale, dt_id(x.dtype), stream())
+    return y
+
+
+def upsample_bwd(dy, scale, dx_out=None, accumulate=False):
+    B, Cc, Ho, Wo = dy.shape
+    H, W = Ho // scale, Wo // scale
+    dx = dx_out if dx_out is not None else empty_nhwc(B, Cc, H, W, dy.dtype, dy.device)
+    call("dy_upsample_nearest_bwd", ptr(dy), ld_of(dy), ptr(dx), ld_of(dx), B, H, W, Cc, scale,
+         1 if (accumulate and dx_out is not None) else 0, dt_id(dy.dtype), stream())
+    return dx
+
+
+def det_maps(maps, strides, nc):
+    """Build the dy_det_maps descriptor for 1-3 NHWC Detect maps [B, 64+nc, h, w]."""
+    m = DetMaps()
+    m.B, m.nc, m.n_levels = maps[0].shape[0], nc, len(maps)
+    m.dtype = dt_id(maps[0].dtype)
+    for i, t in enumerate(maps):
+        m.map[i] = t.data_ptr()
+        m.map_ld[i] = ld_of(t)
+        m.h[i], m.w[i] = t.shape[2], t.shape[3]
+        m.stride[i] = float(strides[i])
+    return m

@@ -1,0 +1,160 @@
+"""Detection criterion on HIP kernels.
+
+Same classes / call signatures as the reference ultralytics/utils/loss.py (v8DetectionLoss :103-193,
+RcoveryDetectionLoss :388-416) and ultralytics/utils/tal.py (TaskAlignedAssigner :59-243).  The whole criterion --
+target grouping, DFL decode, task-aligned assignment, BCE / CIoU / DFL sums and the gradient wrt the three Detect maps --
+runs in libdedark_yolo.so; there are no host syncs on the way (n_max is taken from the CPU-side batch_idx when available).
+"""
+import ctypes as C
+
+import torch
+
+from .. import ops
+from .._C import call
+from ..ops import ld_of, ptr, stream
+
+REG_MAX = 16
+
+
+def _n_max_of(batch_idx, bsz):
+    """Largest number of boxes in one image (host value). batch_idx normally lives on the CPU (dataloader); a GPU tensor
+    costs one sync, like `counts.max()` in the reference (loss.py:130-132)."""
+    if batch_idx.numel() == 0:
+        return 0
+    bi = batch_idx.detach().view(-1)
+    if bi.is_cuda:
+        return int(torch.bincount(bi.long(), minlength=bsz).max().item())
+    return int(torch.bincount(bi.long(), minlength=bsz).max())
+
+
+class _Assignment:
+    __slots__ = ("pred_boxes", "gt", "counts", "target_gt_idx", "fg_mask", "norm", "target_label", "target_box", "n_max")
+
+
+def assign(maps, strides, nc, batch_idx, cls, bboxes, n_max=None):
+    """prepare targets + decode + task-aligned assignment; returns an _Assignment of device tensors."""
+    B = maps[0].shape[0]
+    dev = maps[0].device
+    A = sum(m.shape[2] * m.shape[3] for m in maps)
+    st = stream()
+    img_h, img_w = maps[0].shape[2] * strides[0], maps[0].shape[3] * strides[0]
+    if n_max is None:
+        n_max = _n_max_of(batch_idx, B)
+    n_t = int(batch_idx.numel())
+    f32 = torch.float32
+    bi = batch_idx.to(dev, f32).contiguous().view(-1)
+    cl = cls.to(dev, f32).contiguous().view(-1)
+    bb = bboxes.to(dev, f32).contiguous().view(-1, 4)
+    a = _Assignment()
+    a.n_max = n_max
+    a.gt = torch.empty((B, max(n_max, 1), 5), dtype=f32, device=dev)
+    a.counts = torch.empty(B, dtype=torch.int32, device=dev)
+    call("dy_loss_prepare_targets", ptr(bi) if n_t else None, ptr(cl) if n_t else None, ptr(bb) if n_t else None, n_t, B,
+         max(n_max, 1), float(img_w), float(img_h), ptr(a.gt), ptr(a.counts), st)
+    dm = ops.det_maps(maps, strides, nc)
+    a.pred_boxes = torch.empty((B, A, 4), dtype=f32, device=dev)
+    call("dy_loss_decode", C.byref(dm), ptr(a.pred_boxes), st)
+    a.target_gt_idx = torch.empty((B, A), dtype=torch.int32, device=dev)
+    a.fg_mask = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    a.norm = torch.empty((B, A), dtype=f32, device=dev)
+    a.target_label = torch.empty((B, A), dtype=torch.int32, device=dev)
+    a.target_box = torch.empty((B, A, 4), dtype=f32, device=dev)
+    R = B * max(n_max, 1) * A
+    work_f = torch.empty(2 * R + 2 * B * max(n_max, 1), dtype=f32, device=dev)
+    work_i = torch.empty(R, dtype=torch.int32, device=dev)
+    work_b = torch.empty(R, dtype=torch.uint8, device=dev)
+    call("dy_tal_assign", C.byref(dm), ptr(a.pred_boxes), ptr(a.gt), ptr(a.counts), n_max, ptr(work_f), ptr(work_i),
+         ptr(work_b), ptr(a.target_gt_idx), ptr(a.fg_mask), ptr(a.norm), ptr(a.target_label), ptr(a.target_box), st)
+    return a
+
+
+class _DetLossFn(torch.autograd.Function):
+    """loss, loss_items = f(map0, map1, map2); backward writes d(loss)/d(maps) with one kernel."""
+
+    @staticmethod
+    def forward(ctx, crit, batch, n_maps, *maps):
+        maps = [ops.as_nhwc(m) for m in maps]
+        B = maps[0].shape[0]
+        dev = maps[0].device
+        st = stream()
+        strides = [float(s) for s in crit.stride][:n_maps]
+        a = assign(maps, strides, crit.nc, batch["batch_idx"], batch["cls"], batch["bboxes"], batch.get("n_max"))
+        dm = ops.det_maps(maps, strides, crit.nc)
+        acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        call("dy_loss_fwd", C.byref(dm), ptr(a.pred_boxes), ptr(a.fg_mask), ptr(a.norm), ptr(a.target_label), ptr(a.target_box),
+             ptr(acc), st)
+        rec = batch.get("recovery_loss_batch") if crit.use_recovery else None
+        if rec is not None:
+            rec = rec.detach().to(dev, torch.float32).reshape(-1)
+            rec = rec.mean().reshape(1) if rec.numel() > 1 else rec
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        call("dy_loss_finish", ptr(acc), ptr(rec), float(crit.hyp.box), float(crit.hyp.cls), float(crit.hyp.dfl),
+             float(getattr(crit.hyp, "lrl", 0.0)), B, ptr(out[0:1]), ptr(out[1:4]), st)
+        ctx.crit, ctx.maps, ctx.assign, ctx.acc, ctx.strides = crit, maps, a, acc, strides
+        crit.last_assignment = a
+        loss, items = out[0], out[1:4]
+        ctx.mark_non_differentiable(items)
+        return loss, items
+
+    @staticmethod
+    def backward(ctx, gloss, _gitems):
+        crit, maps, a = ctx.crit, ctx.maps, ctx.assign
+        dev = maps[0].device
+        dt = maps[0].dtype
+        ve = ops.vec_elems(dt)
+        dm = ops.det_maps(maps, ctx.strides, crit.nc)
+        width = 4 * REG_MAX + ops.round_up(crit.nc, ve)
+        dbufs = [ops.empty_nhwc(m.shape[0], width, m.shape[2], m.shape[3], dt, dev) for m in maps]
+        arr_p = (C.c_void_p * 3)(*[d.data_ptr() for d in dbufs] + [None] * (3 - len(dbufs)))
+        arr_l = (C.c_int64 * 3)(*[ld_of(d) for d in dbufs] + [0] * (3 - len(dbufs)))
+        g = gloss.detach().to(torch.float32).reshape(1).contiguous()
+        call("dy_loss_bwd", C.byref(dm), arr_p, arr_l, ptr(a.pred_boxes), ptr(a.fg_mask), ptr(a.norm), ptr(a.target_label),
+             ptr(a.target_box), ptr(ctx.acc), ptr(g), float(crit.hyp.box), float(crit.hyp.cls), float(crit.hyp.dfl), stream())
+        no = 4 * REG_MAX + crit.nc
+        return (None, None, None, *[d[:, :no] for d in dbufs])
+
+
+class v8DetectionLoss:
+    """reference loss.py:103-193. `model.args` must carry .box/.cls/.dfl (and .lrl for the recovery variant)."""
+    use_recovery = False
+
+    def __init__(self, model):
+        m = model.model[-1]
+        self.hyp = model.args
+        self.stride = m.stride
+        self.nc = m.nc
+        self.no = m.no
+        self.reg_max = m.reg_max
+        self.device = next(model.parameters()).device
+        self.use_dfl = m.reg_max > 1
+        self.assigner = TaskAlignedAssigner(topk=10, num_classes=self.nc, alpha=0.5, beta=6.0)
+        self.last_assignment = None
+
+    def __call__(self, preds, batch):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        loss, items = _DetLossFn.apply(self, batch, len(feats), *feats)
+        return loss, items
+
+
+class RcoveryDetectionLoss(v8DetectionLoss):
+    """reference loss.py:388-416: adds lrl * recovery_loss_batch to the total and to the cls item."""
+    use_recovery = True
+
+    def __init__(self, model):
+        super().__init__(model)
+        self.recovery_weight = self.hyp.lrl
+
+
+class TaskAlignedAssigner:
+    """reference tal.py:59-243 (topk must be 10, alpha 0.5, beta 6.0: the constants compiled into the kernel).
+
+    The reference signature takes decoded scores/boxes; the HIP assigner works from the raw Detect maps, so this class
+    exposes `assign_from_maps`; the criterion uses it internally."""
+
+    def __init__(self, topk=13, num_classes=80, alpha=1.0, beta=6.0, eps=1e-9):
+        if (topk, alpha, beta) != (10, 0.5, 6.0):
+            raise NotImplementedError("HIP TaskAlignedAssigner is built for topk=10, alpha=0.5, beta=6.0 (loss.py:120)")
+        self.topk, self.num_classes, self.alpha, self.beta, self.eps = topk, num_classes, alpha, beta, eps
+
+    def assign_from_maps(self, maps, strides, batch_idx, cls, bboxes, n_max=None):
+        return assign([ops.as_nhwc(m) for m in maps], [float(s) for s in strides], self.num_classes, batch_idx, cls, bboxes, n_max)

@@ -1,0 +1,201 @@
+/* dedark_yolo.h -- C-ABI of the MI355X-native Dedark-YOLO hot path (libdedark_yolo.so).
+ *
+ * Drop-in boundary: the reference is 100 % Python on PyTorch; every entry point below replaces the
+ * ATen op sequence issued by one reference function (cited as U/<file>:<lines>, U = ultralytics/ in the reference
+ * tree).  Signatures are plain pointers and sizes -- no torch types.  All pointers are DEVICE pointers unless
+ * named host_*.  Every function enqueues on `stream` (a hipStream_t passed as void*), never synchronises, never
+ * allocates, and returns 0 on success; on failure it returns non-zero and dy_last_error() describes it.
+ *
+ * Layouts: activations are NHWC ("pixel-major"); a tensor view is (pointer to element [n=0,h=0,w=0,c=c0], ld) where
+ * `ld` is the pixel stride in ELEMENTS, so a channel slice of a wider concat buffer is a view with ld = total width.
+ * dtype: DY_F32 (parity path, exact-f32 MFMA 32x32x2) or DY_BF16 (throughput path, MFMA 32x32x16, f32 accumulate).
+ * Weights: f32 OIHW master (the reference state_dict layout) is packed per step into [Cout][KH][KW][Cin] ("KRSC").
+ */
+#ifndef DEDARK_YOLO_H
+#define DEDARK_YOLO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DY_F32 0
+#define DY_BF16 1
+#define DY_ACT_NONE 0
+#define DY_ACT_SILU 1
+#define DY_ACT_LEAKY 2 /* LeakyReLU(0.1) */
+
+const char* dy_last_error(void);
+int dy_version(void);
+
+/* ------------------------------------------------------------------------------------------------ convolution
+ * Replaces nn.Conv2d inside Conv (U/nn/modules/conv.py:38-55), add_conv (U/nn/modules/block.py:24-45),
+ * ConvBlock (U/nn/modules/common.py:9-23), Detect's 1x1 heads (U/nn/modules/head.py:40-46), RFBblock
+ * (block.py:703-734) and nn.Linear of the extractor (common.py:65-66).  Implicit GEMM on MFMA. */
+typedef struct {
+  const void* src;   /* source activations view */
+  int64_t src_ld;
+  int N, Hs, Ws, Cs; /* source geometry; Cs = channels consumed per tap (multiple of 4 for f32, 8 for bf16) */
+  const void* w;     /* packed weights [Cd][KH][KW][Cs], compute dtype */
+  void* dst;         /* destination view */
+  int64_t dst_ld;
+  int Hd, Wd, Cd;    /* destination geometry; Cd = channels produced */
+  int KH, KW, stride, pad, dil;
+  const float* scale; /* optional per-Cd affine applied to the accumulator: v = acc*scale + shift (NULL = 1) */
+  const float* shift; /* optional (bias / folded BN shift) (NULL = 0) */
+  int act;            /* DY_ACT_* applied after the affine */
+  double* stats;      /* optional [2*Cd] (sum, sum of squares) of the RAW accumulator over all pixels (BN batch stats) */
+  int accumulate;     /* 1: dst += result */
+  int dtype;          /* DY_F32 | DY_BF16 (src, w, dst) */
+} dy_conv_desc;
+
+/* forward: dst[n,ho,wo,:] = epilogue( sum_{kh,kw,c} src[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * w[:,kh,kw,c] ) */
+int dy_conv2d_fwd(const dy_conv_desc* d, void* stream);
+/* data gradient: src = dz [N,Hs,Ws,Cs=Cout], w = transposed pack [Cd=Cin][KH][KW][Cs=Cout], dst = dx [N,Hd,Wd,Cd];
+ * dx[n,h,w,:] = sum over taps with (h+pad-kh*dil) % stride == 0 of dz[n,(h+pad-kh*dil)/stride, ...,:] * w */
+int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream);
+/* weight gradient: dw[Cout][KH][KW][Cin] (f32, ACCUMULATED with atomics; zero it first) += sum_pixels dz^T * gather(x).
+ * x view [N,Hi,Wi,Cin], dz view [N,Ho,Wo,Cout]. */
+int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin, const void* dz, int64_t dz_ld, int Ho,
+                    int Wo, int Cout, int KH, int KW, int stride, int pad, int dil, float* dw, int dtype, void* stream);
+/* f32 OIHW [Cout][Cin][KH][KW] -> packed [Cout_pad][KH][KW][Cin_pad] (transposed=0) or [Cin_pad][KH][KW][Cout_pad]
+ * (transposed=1) in `dtype`; padded input/output channels are written as zero. */
+int dy_pack_weight(const float* w_oihw, void* packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int KH, int KW,
+                   int transposed, int dtype, void* stream);
+/* packed f32 grad [Cout][KH][KW][Cin_pad] -> OIHW f32 (overwrite) */
+int dy_unpack_wgrad(const float* dw_packed, float* g_oihw, int Cout, int Cin, int Cin_pad, int KH, int KW, void* stream);
+
+/* ------------------------------------------------------------------------------------ BatchNorm + activation
+ * Replaces nn.BatchNorm2d (train: batch statistics, eps 1e-3, momentum 0.03, U/utils/torch_utils.py:263-265) followed by
+ * SiLU / LeakyReLU(0.1) (conv.py:40,51; block.py:42) and the Bottleneck residual add (block.py:565). */
+/* stats[2C] (from dy_conv2d_fwd) -> scale/shift (y = z*scale + shift), saved mean/invstd, running buffers update. */
+int dy_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                   int C, void* stream);
+/* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
+int dy_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                    float* scale, float* shift, int C, void* stream);
+/* y = act(z*scale + shift) (+ residual); views over `pixels` pixels x C channels */
+int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, const float* shift, int act, const void* residual,
+                  int64_t res_ld, void* y, int64_t y_ld, int64_t pixels, int C, int dtype, void* stream);
+/* backward pass 1: sums[0:C] = sum g, sums[C:2C] = sum g*zhat with g = dy*act'(u), u = z*scale+shift,
+ * zhat = (z-mean)*invstd (has_bn) ; without BN only sum g (bias gradient). `sums` (double) must be zeroed. */
+int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int act, int has_bn, double* sums,
+                         int64_t pixels, int C, int dtype, void* stream);
+/* backward pass 2: dz = gamma*invstd*(g - sum_g/M - zhat*sum_gz/M)  (has_bn) or dz = g; also dgamma = sum_gz,
+ * dbeta = sum_g (written when the pointers are non-NULL, by block 0). */
+int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* gamma, int act, int has_bn,
+                        const double* sums, void* dz, int64_t dz_ld, float* dgamma, float* dbeta, int64_t pixels, int C,
+                        int dtype, void* stream);
+
+/* ----------------------------------------------------------------------------- pooling / resampling / concat
+ * SPPF's 3 chained MaxPool2d(5,1,2) (block.py:331-338), ASFF's MaxPool2d(2,2) and max_pool2d(3,2,1) (block.py:58,85-86),
+ * nn.Upsample / F.interpolate nearest (yolov8.yaml head; block.py:91,97,99), torch.cat (conv.py:473), x + y. */
+/* argmax (optional) stores the window offset kh*k+kw of the FIRST maximum in scan order, one byte per output element */
+int dy_maxpool_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, uint8_t* argmax, int N, int H, int W, int C, int k,
+                   int stride, int pad, int Ho, int Wo, int dtype, void* stream);
+/* dx (+)= adjoint of the pooling through argmax (gather form, no atomics) */
+int dy_maxpool_bwd(const void* dy, int64_t dy_ld, const uint8_t* argmax, void* dx, int64_t dx_ld, int N, int H, int W, int C,
+                   int k, int stride, int pad, int Ho, int Wo, int accumulate, int dtype, void* stream);
+int dy_upsample_nearest_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int H, int W, int C, int scale,
+                            int dtype, void* stream);
+/* dx (+)= sum over the scale x scale children of dy */
+int dy_upsample_nearest_bwd(const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int N, int H, int W, int C, int scale,
+                            int accumulate, int dtype, void* stream);
+/* strided copy / add of `pixels` x C channel slabs (concat writes, chunk reads, gradient accumulation) */
+int dy_copy2d(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int64_t pixels, int C, int accumulate, int dtype,
+              void* stream);
+int dy_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* ASFF blend (block.py:103-111): w = softmax(logits[.,3]); out = sum_i w_i * x_i */
+int dy_asff_fuse_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, const void* x2, int64_t ld2,
+                     const void* logits, int64_t ldl, void* out, int64_t ldo, int64_t pixels, int C, int dtype, void* stream);
+int dy_asff_fuse_bwd(const void* dout, int64_t lddo, const void* x0, int64_t ld0, const void* x1, int64_t ld1,
+                     const void* x2, int64_t ld2, const void* logits, int64_t ldl, void* dx0, int64_t ldd0, void* dx1,
+                     int64_t ldd1, void* dx2, int64_t ldd2, void* dlogits, int64_t lddl, int64_t pixels, int C,
+                     int acc0, int acc1, int acc2, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------- low-light front-end
+ * lowlight_recovery.forward (U/nn/modules/llie.py:17-54) and the five filters of U/nn/modules/filtersB.py. */
+/* NCHW f32 [B,3,H,W] -> NHWC with 8 channels (3 used, 5 zero) in `dtype`; optional bilinear resize to (Ho,Wo)
+ * with align_corners=False (llie.py:43). Ho==H && Wo==W is a plain relayout. */
+int dy_image_to_nhwc8(const float* x, int B, int H, int W, void* y, int Ho, int Wo, int dtype, void* stream);
+/* adjoint of the bilinear resize: dx[B,3,H,W] f32 += resize^T(dy NHWC8 f32) */
+int dy_resize_bwd(const float* dy_nhwc, int dy_ld, int B, int H, int W, int Ho, int Wo, float* dx, void* stream);
+/* feat[B, feat_ld >= 15] -> params[B,8] = (omega, s_r, s_g, s_b, gamma, alpha, lambda, 0)  (filtersB.py regressors);
+ * the backward writes all feat_ld columns of dfeat (zeros beyond the used slots) */
+int dy_filter_params_fwd(const float* feat, int feat_ld, float* params, int B, void* stream);
+int dy_filter_params_bwd(const float* feat, int feat_ld, const float* dparams, float* dfeat, int B, void* stream);
+/* DeDark -> WB -> Gamma -> Contrast pointwise chain (filtersB.py:190-303) x -> s4 ; A [B,3] or NULL (0.8);
+ * IcA [B,H,W] or NULL (0.5) */
+int dy_filters_pointwise_fwd(const float* x, const float* params, const float* A, const float* IcA, float* s4, int B,
+                             int H, int W, void* stream);
+/* USM (filtersB.py:153-175) as a separable 25-tap gaussian with reflect halo: out = (s4 - blur)*lambda + s4.
+ * Writes out NCHW f32 (optional), the NHWC8 copy in `dtype` for the stem conv (optional), and hp = s4 - blur (optional). */
+int dy_usm_fwd(const float* s4, const float* params, float* out_nchw, void* out_nhwc8, float* hp, int B, int H, int W,
+               int dtype, void* stream);
+/* USM backward: ds4 = dout*(1+lambda) - lambda*blur^T(dout); dparams[b,6] += sum dout*hp.  dout is either NCHW f32
+ * (dout_nchw) or a padded NHWC view in `dtype` with pixel stride dout_ld (dout_nhwc); exactly one is non-NULL. */
+int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc, int dout_ld, const float* hp, const float* params, float* ds4,
+               float* dparams, int B, int H, int W, int dtype, void* stream);
+/* pointwise backward: recomputes the chain from x, consumes ds4, writes dx (overwrite or +=; NULL = not needed) and
+ * accumulates dparams[b, 0..5] */
+int dy_filters_pointwise_bwd(const float* x, const float* params, const float* A, const float* IcA, const float* ds4,
+                             float* dx, float* dparams, int B, int H, int W, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------ detection loss
+ * v8DetectionLoss / RcoveryDetectionLoss (U/utils/loss.py:103-193,388-416), TaskAlignedAssigner (U/utils/tal.py),
+ * bbox_iou CIoU (U/utils/metrics.py:75-128), make_anchors / dist2bbox (tal.py:246-271). */
+typedef struct {
+  const void* map[3]; /* Detect train outputs, NHWC views [B, h_l*w_l, no], no = 64+nc */
+  int64_t map_ld[3];
+  int h[3], w[3];
+  float stride[3];
+  int B, nc, n_levels, dtype;
+} dy_det_maps;
+
+/* group targets per image: rows (batch_idx, cls, cx, cy, w, h normalised) -> gt[B][n_max][5] = (cls, x1,y1,x2,y2 px),
+ * counts[B]; order within an image is preserved (loss.py:124-139). */
+int dy_loss_prepare_targets(const float* batch_idx, const float* cls, const float* bboxes, int n_targets, int B,
+                            int n_max, float img_w, float img_h, float* gt, int32_t* counts, void* stream);
+/* decode (loss.py:141-146): pred_boxes[B,A,4] xyxy in grid units, via softmax over 16 bins . arange */
+int dy_loss_decode(const dy_det_maps* m, float* pred_boxes, void* stream);
+/* task-aligned assignment (tal.py:83-127; topk 10, alpha .5, beta 6).  Scratch: work_f [2*R + 2*B*n_max] floats,
+ * work_i [R] int32, work_b [R] bytes with R = B*n_max*A.  Outputs: target_gt_idx[B,A] i32, fg_mask[B,A] u8,
+ * norm[B,A] f32 (= target_scores at the assigned label, 0 elsewhere), target_label[B,A] i32, target_box[B,A,4] f32 (px).
+ * top-10 ties follow std::partial_sort as torch.topk does on CPU for A >= 640. */
+int dy_tal_assign(const dy_det_maps* m, const float* pred_boxes, const float* gt, const int32_t* counts, int n_max,
+                  float* work_f, int32_t* work_i, uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm,
+                  int32_t* target_label, float* target_box, void* stream);
+/* loss sums: acc[0]=sum target_scores, acc[1]=BCE sum, acc[2]=sum (1-ciou)*w, acc[3]=sum dfl*w (acc zeroed first) */
+int dy_loss_fwd(const dy_det_maps* m, const float* pred_boxes, const uint8_t* fg_mask, const float* norm,
+                const int32_t* target_label, const float* target_box, double* acc, void* stream);
+/* finish: loss_out[0] = (box*hb + cls*hc + dfl*hd)*B + lrl*rec ; items[3] = (box*hb, cls*hc + lrl*rec, dfl*hd) */
+int dy_loss_finish(const double* acc, const float* recovery, float hyp_box, float hyp_cls, float hyp_dfl, float lrl,
+                   int B, float* loss_out, float* items, void* stream);
+/* gradient wrt the three maps (written in `dtype`, every element), scaled by *grad_out (device scalar) */
+int dy_loss_bwd(const dy_det_maps* m, void* const dmap[3], const int64_t dmap_ld[3], const float* pred_boxes,
+                const uint8_t* fg_mask, const float* norm, const int32_t* target_label, const float* target_box,
+                const double* acc, const float* grad_out, float hyp_box, float hyp_cls, float hyp_dfl, void* stream);
+/* Detect eval decode (head.py:66-93): y[B, 4+nc, A] f32 = cat(xywh*stride, sigmoid(cls)) */
+int dy_detect_decode(const dy_det_maps* m, float* y, void* stream);
+/* preprocess_batch tensor part (U/models/yolo/detect/train.py:70-111): u8 NCHW -> f32 /255 (^gamma), mse accumulators */
+int dy_preprocess_batch(const uint8_t* img, float* img_out, float* clean_out, float dark_param, int lowlight, int dedark,
+                        double* mse_acc, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimizer
+ * BaseTrainer.optimizer_step (U/engine/trainer.py:459-467): clip_grad_norm_(10.0) + SGD(nesterov) / AdamW step +
+ * ModelEMA.update (U/utils/torch_utils.py:360-371) on flat f32 parameter ranges. */
+int dy_sumsq(const float* g, int64_t n, double* acc, void* stream);
+/* clip coefficient = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq != NULL; ema may be NULL */
+int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, float lr, float momentum, float weight_decay,
+                int nesterov, float ema_decay, const double* sumsq, float max_norm, int64_t n, void* stream);
+int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float ema_decay, const double* sumsq, float max_norm, int64_t n,
+                  void* stream);
+int dy_frontend_init(void); /* uploads the gaussian taps (call once per process, outside graph capture) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""CPU tests of the host side: registry / state_dict drop-in contract, C-ABI library exports, layout helpers.
+No kernel is launched here (there is no GPU in the build container)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT, load_yaml
+
+YAMLS = [("yolov8ori.yaml", "n"), ("yolov8-lowlight.yaml", "n"), ("yolov8.yaml", "l"), ("yolov8-RBF-ASFF.yaml", "l")]
+
+
+@pytest.mark.parametrize("yml,scale", YAMLS)
+def test_state_dict_names_match_reference_layout(yml, scale):
+    """The product model must expose exactly the reference's state_dict keys/shapes (oracle.param_shapes is pinned to the
+    reference by the golden tests: its rng_fill dict loads strictly into the reference modules)."""
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from oracle import model as om
+    cfg = load_yaml(yml)
+    cfg["scale"] = scale
+    plan, save = om.build_plan(cfg, scale=scale, nc=20)
+    want = om.param_shapes(plan)
+    model = DetectionModel(dict(cfg), nc=20)
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert set(have) == set(want), (sorted(set(want) - set(have))[:5], sorted(set(have) - set(want))[:5])
+    for k in want:
+        assert tuple(want[k]) == have[k], k
+    assert set(model.save) == set(save)
+    assert [float(s) for s in model.stride] == [8.0, 16.0, 32.0]
+
+
+def test_param_counts():
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    m = DetectionModel("yolov8l.yaml", nc=20)
+    assert sum(p.numel() for p in m.parameters()) == 51776780
+    m = DetectionModel("yolov8nori.yaml", nc=20)
+    assert sum(p.numel() for p in m.parameters()) == 3014748
+
+
+def test_repo_yaml_only_builds_at_scale_l_contract():
+    """AsffTribeLevel hard-codes (512, 512, 256) (reference block.py:52): at scale n the graph is inconsistent."""
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    m = DetectionModel("yolov8n.yaml", nc=20)          # constructing is possible, running would raise on channel mismatch
+    assert m.model[23].inter_dim == 512 and m.model[22].cv2.conv.out_channels != 512
+
+
+def test_detect_bias_init_and_bn_constants():
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    import math
+    m = DetectionModel("yolov8nori.yaml", nc=20)
+    det = m.model[-1]
+    assert torch.allclose(det.cv2[0][-1].bias, torch.ones(64))
+    assert abs(float(det.cv3[1][-1].bias[0]) - math.log(5 / 20 / (640 / 16) ** 2)) < 1e-6
+    bns = [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)]
+    assert bns and all(b.eps == 1e-3 and b.momentum == 0.03 for b in bns)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/dedark_yolo.h <-> libdedark_yolo.so <-> ctypes table agree (symbol names and argument counts)."""
+    from dedark_yolo_amd import _C
+    hdr = open(os.path.join(ROOT, "include", "dedark_yolo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(dy_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    assert len(decls) > 30
+    table = dict(_C._SIGS)
+    for name, n in decls.items():
+        if name == "dy_last_error":
+            continue
+        assert name in table, f"{name} declared in the header but missing from the ctypes table"
+        assert len(table[name]) == n, f"{name}: header has {n} args, ctypes table {len(table[name])}"
+    assert set(table) <= set(decls), set(table) - set(decls)
+    lib = _C.lib()                       # raises if the .so is missing or a symbol is not exported
+    assert lib.dy_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True).stdout
+    for name in decls:
+        assert re.search(rf"\b{name}\b", out), f"{name} not exported"
+
+
+def test_product_path_has_no_cpu_fallback():
+    from dedark_yolo_amd.nn.modules import Conv
+    c = Conv(8, 8, 3, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        c(torch.zeros(1, 8, 8, 8))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "dedark_yolo_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_nhwc_view_helpers():
+    from dedark_yolo_amd import ops
+    t = torch.empty((2, 16, 5, 7), memory_format=torch.channels_last)
+    assert ops.ld_of(t) == 16 and ops.ld_of(t[:, 4:12]) == 16
+    with pytest.raises(RuntimeError):
+        ops.ld_of(torch.empty(2, 16, 5, 7))
+    z = ops.zeros_nhwc(1, 8, 3, 3, torch.float32, "cpu")
+    assert ops.ld_of(z) == 8 and z.shape == (1, 8, 3, 3)
+    assert ops.round_up(20, 8) == 24 and ops.vec_elems(torch.bfloat16) == 8
+
+
+def test_yaml_loader_and_scale_guess():
+    from dedark_yolo_amd.nn.tasks import guess_model_scale, yaml_model_load
+    d = yaml_model_load("yolov8l.yaml")
+    assert d["scale"] == "l" and d["backbone"][0][2] == "lowlight_recovery"
+    assert guess_model_scale("yolov8n-lowlight.yaml") == "n"
+    with pytest.raises(FileNotFoundError):
+        yaml_model_load("yolov9q.yaml")
