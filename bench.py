@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the Dedark-YOLO hot path on MI355X (BASELINE.json metric: training img/s at 640x640).
+
+  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one training pass of the hot path over one synthetic batch that is ALREADY RESIDENT IN HBM:
+preprocess_batch (uint8 -> /255 -> x^gamma, recovery mse) -> lowlight_recovery -> YOLOv8 backbone/neck/Detect ->
+RcoveryDetectionLoss + TaskAlignedAssigner -> backward -> (N>1: bucketed RCCL all-reduce overlapped with backward) ->
+fused clip + SGD-nesterov + EMA.  Workload at N=1: BASELINE config C2 (YOLOv8n + lowlight_recovery, 640x640, bf16,
+batch 32 per GPU, gamma ~ U(5,10) per batch, nc=20); weak scaling (per-GPU batch fixed).
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, timed live with events on the
+launch stream over extra instrumented steps after the timed region) and, at N=1, `cpu_baseline` (the CPU oracle = our
+port of the reference path, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy rate)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+MFMA_F32_PEAK_TF = 157.3
+
+
+def synth_batch(seed, B, S, nc, device):
+    """SURVEY 8(d) synthetic law: clean ~ U[0,1) stored as uint8, 1..8 boxes/image, cls ~ U{0..nc-1}, centres U(.2,.8),
+    sizes U(.05,.35) clipped to the image; gamma ~ U(5,10) per batch."""
+    g = np.random.default_rng(seed)
+    img = torch.from_numpy((g.random((B, 3, S, S), dtype=np.float32) * 255).astype(np.uint8))
+    bi, cls, bb = [], [], []
+    for b in range(B):
+        for _ in range(int(g.integers(1, 9))):
+            cx, cy = g.uniform(0.2, 0.8, 2)
+            w, h = g.uniform(0.05, 0.35, 2)
+            x1, y1, x2, y2 = max(cx - w / 2, 0), max(cy - h / 2, 0), min(cx + w / 2, 1), min(cy + h / 2, 1)
+            bi.append(b)
+            cls.append(int(g.integers(0, nc)))
+            bb.append([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1])
+    bi_t = torch.tensor(bi, dtype=torch.float32)
+    n_max = int(torch.bincount(bi_t.long(), minlength=B).max())
+    return dict(img=img.to(device), batch_idx=bi_t.to(device), cls=torch.tensor(cls, dtype=torch.float32).view(-1, 1).to(device),
+                bboxes=torch.tensor(bb, dtype=torch.float32).view(-1, 4).to(device), n_max=n_max,
+                gamma=float(g.uniform(5.0, 10.0)))
+
+
+def cpu_baseline(nc, S, seconds_budget=25.0):
+    """The oracle (CPU port of the reference path, oracle/) doing the same training step in fp32 on the host cores.
+    Bounded sample: B=4 images per step, 2 warm-up steps, then steps until ~seconds_budget of CPU time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import loss as oloss
+    from oracle import model as om
+    from util import load_yaml
+    threads = torch.get_num_threads()
+    cfg = load_yaml("yolov8-lowlight.yaml")
+    plan, save = om.build_plan(cfg, scale="n", nc=nc)
+    sd = om.rng_fill(om.param_shapes(plan), 0)
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and v.ndim > 0 and ".dfl." not in k and "running_" not in k:
+            v.requires_grad_(True)
+            params.append(v)
+    B = 4
+    b = synth_batch(99, B, S, nc, "cpu")
+    hyp = oloss.default_hyp()
+
+    def step():
+        img, clean, rec = oloss.preprocess_batch(b["img"], b["gamma"], True, True)
+        maps = om.forward(plan, save, sd, img, True)
+        strides = [float(S // m.shape[2]) for m in maps]
+        batch = dict(batch_idx=b["batch_idx"], cls=b["cls"], bboxes=b["bboxes"], recovery_loss_batch=rec)
+        loss, _ = oloss.recovery_detection_loss(maps, batch, strides, nc, hyp)
+        loss.backward()
+        with torch.no_grad():
+            for p in params:
+                p -= 0.01 * p.grad
+                p.grad = None
+
+    for _ in range(2):
+        step()
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 40:
+            break
+    return dict(value=round(B * n / el, 3), unit="img/s", cores=threads, kind="port",
+                sample=f"oracle (CPU port of the reference path) fp32, YOLOv8n+lowlight_recovery 640x640, batch {B}, {n} timed steps "
+                       f"after 2 warm-up, fwd+loss+bwd+SGD, torch {torch.__version__} with {threads} threads")
+
+
+def kernel_profile(trainer, batches, steps=3):
+    """Per-C-ABI-entry timing with events on the launch stream (torch's current stream) over `steps` extra steps."""
+    from dedark_yolo_amd import _C
+    _C._prof = []
+    for i in range(steps):
+        b = dict(batches[i % len(batches)])
+        trainer.args.dark_param = b["gamma"]
+        trainer.train_step(b)
+    torch.cuda.synchronize()
+    rec, _C._prof = _C._prof, None
+    agg = {}
+    for name, e0, e1, meta in rec:
+        key = name + ("/" + meta["dtype"].replace("torch.", "") if meta else "")
+        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, meta_n=0))
+        a["ms"] += e0.elapsed_time(e1)
+        a["n"] += 1
+        if meta:
+            a["flops"] += meta["flops"]
+            a["bytes"] += meta["bytes"]
+            a["meta_n"] += 1
+    return agg, steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--model", default="yolov8n-lowlight.yaml")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl")
+
+    from dedark_yolo_amd.engine.trainer import DetectionTrainer, get_cfg
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    nc = 20
+    torch.manual_seed(0)
+    cfg = get_cfg(dict(model=args.model, dtype=args.dtype, optimizer="SGD", batch=args.batch * world, imgsz=args.imgsz,
+                       lowlight_FLAG=True, dedark_FLAG=True))
+    trainer = DetectionTrainer(cfg)
+    trainer.setup(DetectionModel(args.model, nc=nc))
+    batches = [synth_batch(1234 + 17 * rank + i, args.batch, args.imgsz, nc, device) for i in range(4)]
+
+    def run(n):
+        for i in range(n):
+            b = dict(batches[i % len(batches)])
+            trainer.args.dark_param = b["gamma"]
+            loss, items = trainer.train_step(b)
+        return loss
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t)
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit(f"non-finite loss {final_loss}")
+
+    out = dict(metric="training img/s at 640x640", value=round(args.batch * world * args.steps / el, 2), unit="img/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1000 * el / args.steps, 3),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+               config=dict(workload=f"BASELINE C2: {args.model} (YOLOv8n + lowlight_recovery front-end), {args.imgsz}x{args.imgsz}, "
+                                    f"{args.dtype}, batch {args.batch}/GPU, nc={nc}, gamma~U(5,10), full train step "
+                                    "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, inputs resident in HBM",
+                           global_batch=args.batch * world, parallelism=f"dp{world}"),
+               final_loss=round(final_loss, 4))
+
+    if rank == 0 and not args.no_roofline:
+        agg, psteps = kernel_profile(trainer, batches)
+        tot = sum(a["ms"] for a in agg.values())
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+        name, a = next(((k, v) for k, v in top if v["meta_n"] == v["n"] and v["n"] > 0), top[0])
+        avg_s = a["ms"] / a["n"] / 1e3
+        intensity = a["flops"] / max(a["bytes"], 1.0)
+        bf16 = "bfloat16" in name
+        ridge = (MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if a["flops"] > 0 and intensity > ridge:
+            ach = a["flops"] / a["n"] / avg_s / 1e12
+            peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4))
+        else:
+            ach = a["bytes"] / a["n"] / avg_s / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+        roof.update(kernel=name, launches_per_step=a["n"] // psteps, avg_launch_us=round(avg_s * 1e6, 2),
+                    share_of_kernel_time=round(a["ms"] / tot, 3), flop_per_byte=round(intensity, 1), traffic=None)
+        out["roofline"] = roof
+        out["kernel_time_breakdown_ms_per_step"] = {k: round(v["ms"] / psteps, 3) for k, v in top[:10]}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(nc, args.imgsz)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

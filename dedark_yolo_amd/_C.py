@@ -65,8 +65,9 @@ _SIGS = {
     "dy_detect_decode": [C.POINTER(DetMaps), vp, vp],
     "dy_preprocess_batch": [vp, vp, vp, f32, i32, i32, vp, i64, vp],
     "dy_sumsq": [vp, i64, vp, vp],
-    "dy_sgd_step": [vp, vp, vp, vp, f32, f32, f32, i32, f32, vp, f32, i64, vp],
-    "dy_adamw_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, vp, f32, i64, vp],
+    "dy_sgd_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],
+    "dy_adamw_step": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],
+    "dy_ema_lerp": [vp, vp, f32, i64, vp],
 }
 
 _lib = None
@@ -94,8 +95,29 @@ def exported_symbols():
     return ["dy_last_error"] + list(_SIGS)
 
 
+_prof = None          # list of (name, start_event, end_event, meta) while bench.py's per-kernel timing is active
+_next_meta = None
+
+
 def call(name, *args):
+    global _next_meta
     L = lib()
-    rc = getattr(L, name)(*args)
+    if _prof is None:
+        rc = getattr(L, name)(*args)
+    else:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                      # kernels are launched on torch's current stream, so these events bracket them
+        rc = getattr(L, name)(*args)
+        e1.record()
+        _prof.append((name, e0, e1, _next_meta))
+        _next_meta = None
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {L.dy_last_error().decode()}")
+
+
+def set_meta(**kw):
+    """Algorithmic work of the NEXT call (flops / bytes), recorded only while profiling."""
+    global _next_meta
+    if _prof is not None:
+        _next_meta = kw

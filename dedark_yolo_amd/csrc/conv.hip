@@ -69,10 +69,12 @@ __device__ inline void mma_step(const char* As, const char* Bs, int a_row0, int 
                                                               acc[i][j], 0, 0, 0);
         } else {
           // lane half h holds k = kk*8 + 4h + q; A and B use the same k permutation, so the sum is exact
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, af[i][q]),
-                                                             __builtin_bit_cast(float, bfr[j][q]), acc[i][j], 0, 0, 0);
+          const f32x4 fa = __builtin_bit_cast(f32x4, af[i]);
+          const f32x4 fb = __builtin_bit_cast(f32x4, bfr[j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc[i][j], 0, 0, 0);
         }
       }
   }

@@ -1,0 +1,74 @@
+"""`YOLO` facade with the reference call surface (ultralytics/engine/model.py:29-416): YOLO(model), .train(**kw), .val(**kw),
+.load(), .fuse(); detect task only (the other tasks are outside the hot path)."""
+from pathlib import Path
+
+import torch
+
+from ..nn.tasks import DetectionModel
+from .trainer import DetectionTrainer, get_cfg
+
+
+class YOLO:
+    def __init__(self, model="yolov8l.yaml", task=None):
+        if task not in (None, "detect"):
+            raise NotImplementedError("only the detect task is on the Dedark-YOLO hot path")
+        self.task = "detect"
+        self.trainer = None
+        self.overrides = {}
+        suffix = Path(str(model)).suffix
+        if suffix == ".yaml":
+            self._new(model)
+        elif suffix in (".pt", ".pth"):
+            self._load(model)
+        else:
+            raise FileNotFoundError(f"'{model}': expected a model .yaml or a state_dict checkpoint .pt")
+
+    def _new(self, cfg):
+        self.cfg = cfg
+        self.model = DetectionModel(cfg)
+        self.overrides["model"] = cfg
+
+    def _load(self, weights):
+        ck = torch.load(weights, map_location="cpu", weights_only=True)
+        cfg = ck.get("yaml") or ck.get("cfg")
+        self.model = DetectionModel(cfg, nc=ck.get("nc"))
+        self.model.load(ck["state_dict"])
+        self.cfg = cfg
+        self.overrides["model"] = cfg
+
+    def __call__(self, source, **kw):
+        return self.predict(source, **kw)
+
+    def load(self, weights):
+        self.model.load(weights)
+        return self
+
+    def fuse(self):
+        self.model.fuse()
+        return self
+
+    def train(self, loader=None, **kwargs):
+        """model.train(data=..., epochs=..., imgsz=..., batch=..., device=...) -- `loader` is any iterable of reference-schema batch
+        dicts (the cv2 data pipeline is outside the hot path)."""
+        ov = dict(self.overrides)
+        ov.update(kwargs)
+        self.trainer = DetectionTrainer(get_cfg(ov))
+        if loader is None:
+            raise ValueError("pass loader=<iterable of batch dicts>; dataset decoding/augmentation is outside the hot path")
+        self.trainer.setup(self.model, total_iterations=len(loader) * self.trainer.args.epochs)
+        return self.trainer.train(loader)
+
+    def val(self, loader=None, **kwargs):
+        from .validator import DetectionValidator
+        ov = dict(self.overrides)
+        ov.update(kwargs)
+        v = DetectionValidator(get_cfg(ov))
+        return v(self.model, loader)
+
+    def predict(self, source, **kw):
+        self.model.eval()
+        with torch.no_grad():
+            return self.model(source)
+
+    def save(self, path):
+        torch.save(dict(state_dict=self.model.state_dict(), yaml=self.model.yaml, nc=self.model.yaml["nc"]), path)

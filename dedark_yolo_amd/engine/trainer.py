@@ -1,0 +1,283 @@
+"""Training harness of the hot path: the caller contract of the reference BaseTrainer / DetectionTrainer
+(ultralytics/engine/trainer.py:191-266,292-359,459-467,611-665; ultralytics/models/yolo/detect/train.py:70-111,123-129;
+ModelEMA ultralytics/utils/torch_utils.py:344-377) re-designed around flat HBM-resident state:
+
+  * every trainable parameter, its gradient, momentum and EMA live in ONE flat f32 buffer each (module order); the conv /
+    BN kernels write gradients straight into it, the optimizer + clip + EMA is one fused kernel (3 launches per step);
+  * data parallel: one process per GPU, gradients are SUM-all-reduced over RCCL in layer-aligned buckets that are issued
+    as soon as backward has passed the bucket (overlap with the remaining wgrad kernels); loss.py's per-rank normaliser
+    and `loss *= world_size` + DDP mean (trainer.py:334-335) == plain sum of per-rank gradients;
+  * preprocess_batch's tensor part (uint8 -> /255 -> x^dark_param, recovery mse) is one HIP kernel; the numpy dark-channel
+    branch of the reference (train.py:81-97) is dead downstream and reads uninitialised memory: not reproduced.
+"""
+import math
+import os
+from pathlib import Path
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+import yaml
+
+from .. import ops
+from .._C import call
+from ..nn.modules import DyModule
+from ..nn.tasks import DetectionModel
+from ..ops import ptr, stream
+
+DEFAULT_CFG_PATH = Path(__file__).resolve().parent.parent / "cfg" / "default.yaml"
+
+
+def get_cfg(overrides=None):
+    with open(DEFAULT_CFG_PATH) as f:
+        d = yaml.safe_load(f)
+    for k, v in (overrides or {}).items():
+        d[k] = v
+    return SimpleNamespace(**d)
+
+
+class FlatState:
+    """Flat parameter / gradient / optimizer-state storage for a model (module order, 16-byte aligned slots)."""
+
+    def __init__(self, model, with_ema=True):
+        import torch.nn as nn
+        params, gids = [], []
+        bn_types = tuple(v for k, v in nn.__dict__.items() if "Norm" in k and isinstance(v, type))
+        seen = set()
+        self.layer_ranges = []                       # (top-level layer index, start, end) in elements
+        off = 0
+        slots = []
+        for li, layer in enumerate(model.model):
+            start = off
+            for mod in layer.modules():
+                for name, p in mod.named_parameters(recurse=False):
+                    if not p.requires_grad or id(p) in seen:
+                        continue
+                    seen.add(id(p))
+                    g = 2 if name == "bias" else (1 if isinstance(mod, bn_types) else 0)     # trainer.py:626-634
+                    n = p.numel()
+                    slots.append((p, off, n, g))
+                    off += ops.round_up(n, 4)
+            self.layer_ranges.append((li, start, off))
+        self.n = off
+        dev = next(model.parameters()).device
+        f32 = torch.float32
+        self.p = torch.zeros(off, dtype=f32, device=dev)
+        self.g = torch.zeros(off, dtype=f32, device=dev)
+        self.m = torch.zeros(off, dtype=f32, device=dev)
+        self.m2 = None
+        self.gid = torch.zeros(off, dtype=torch.uint8, device=dev)
+        for p, o, n, g in slots:
+            self.p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + n].view(p.shape)
+            p.grad = self.g[o:o + n].view(p.shape)
+            p._dy_direct = True
+            self.gid[o:o + n] = g
+        self.slots = slots
+        self.ema = self.p.clone() if with_ema else None
+        # float buffers (BN running statistics) take part in the EMA like in the reference (state_dict based)
+        bufs = [b for b in model.buffers() if b.dtype.is_floating_point and b.numel() > 0 and b.is_cuda]
+        self.buf_list = bufs
+        nb = sum(ops.round_up(b.numel(), 4) for b in bufs)
+        self.buf_flat = torch.zeros(nb, dtype=f32, device=dev)
+        o = 0
+        for b in bufs:
+            n = b.numel()
+            self.buf_flat[o:o + n].copy_(b.reshape(-1))
+            b.data = self.buf_flat[o:o + n].view(b.shape)
+            o += ops.round_up(n, 4)
+        self.buf_ema = self.buf_flat.clone() if with_ema else None
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.bump_weights_epoch()
+
+    def ema_state_dict(self, model):
+        """state_dict of the EMA model (for checkpoints / validation)."""
+        sd = {}
+        names = {id(p): k for k, p in model.named_parameters()}
+        for p, o, n, _ in self.slots:
+            sd[names[id(p)]] = self.ema[o:o + n].view(p.shape).clone()
+        bnames = {id(b): k for k, b in model.named_buffers()}
+        o = 0
+        for b in self.buf_list:
+            n = b.numel()
+            sd[bnames[id(b)]] = self.buf_ema[o:o + n].view(b.shape).clone()
+            o += ops.round_up(n, 4)
+        return sd
+
+
+class GradBuckets:
+    """Layer-aligned gradient buckets.  The all-reduce(sum) of a bucket is issued from inside the backward pass as soon as
+    every parameterised layer of the bucket has produced its gradients (RCCL waits on the compute stream at issue time and
+    runs on its own stream, so it overlaps the remaining dgrad / wgrad kernels)."""
+
+    def __init__(self, flat, model, bucket_bytes=32 << 20):
+        self.flat = flat
+        self.works = []
+        self.buckets = []          # dict(start, end, layers)
+        cur_end, layers = flat.n, []
+        for li, s, e in reversed(flat.layer_ranges):
+            if e > s:
+                layers.append(li)
+            if (cur_end - s) * 4 >= bucket_bytes or li == 0:
+                if cur_end > s:
+                    self.buckets.append(dict(start=s, end=cur_end, layers=set(layers)))
+                cur_end, layers = s, []
+        self.owner = {li: b for b in self.buckets for li in b["layers"]}
+        self._reset()
+        for li, layer in enumerate(model.model):
+            if li in self.owner:
+                layer._dy_after_backward = (lambda idx: (lambda: self._layer_done(idx)))(li)
+
+    def _reset(self):
+        for b in self.buckets:
+            b["left"] = len(b["layers"])
+
+    def _layer_done(self, li):
+        b = self.owner[li]
+        b["left"] -= 1
+        if b["left"] == 0:
+            self.works.append(dist.all_reduce(self.flat.g[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for b in self.buckets:              # a layer that took no part in this backward (should not happen) is reduced here
+            if b["left"] > 0:
+                self.works.append(dist.all_reduce(self.flat.g[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        self._reset()
+
+
+class DetectionTrainer:
+    """Minimal, faithful training loop for the detect task.  `train(loader)` consumes batch dicts with the reference schema
+    (img uint8 [B,3,H,W] RGB, cls [N,1], bboxes [N,4] normalised xywh, batch_idx [N])."""
+
+    def __init__(self, cfg=None, overrides=None):
+        self.args = cfg if cfg is not None else get_cfg(overrides)
+        self.rank = int(os.environ.get("RANK", -1))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        self.world_size = int(os.environ.get("WORLD_SIZE", 1))
+        self.device = torch.device("cuda", self.local_rank)
+        self.model = None
+        self.flat = None
+        self.buckets = None
+        self.updates = 0
+        self.step_count = 0
+        self.mse_acc = None
+
+    # ---------------------------------------------------------------- setup
+    def get_model(self, cfg=None, weights=None, nc=None):
+        model = DetectionModel(cfg or self.args.model, nc=nc)
+        if weights is not None:
+            model.load(weights)
+        return model
+
+    def setup(self, model=None, nc=None, total_iterations=None):
+        torch.cuda.set_device(self.device)
+        ops.set_compute_dtype(torch.bfloat16 if str(getattr(self.args, "dtype", "fp32")) in ("bf16", "bfloat16") else torch.float32)
+        self.model = (model if model is not None else self.get_model(nc=nc)).to(self.device)
+        self.model.args = self.args
+        self.model.train()
+        if self.world_size > 1:
+            if not dist.is_initialized():
+                dist.init_process_group("nccl" if dist.is_nccl_available() else "gloo")
+            for t in list(self.model.parameters()) + list(self.model.buffers()):       # K3: one broadcast of the start state
+                dist.broadcast(t.data, src=0)
+        self.flat = FlatState(self.model, with_ema=True)
+        if self.world_size > 1:
+            self.buckets = GradBuckets(self.flat, self.model)
+        a = self.args
+        name = a.optimizer
+        if name == "auto":                                       # trainer.py:617-623
+            nc_ = getattr(self.model.model[-1], "nc", 10)
+            lr_fit = round(0.002 * 5 / (4 + nc_), 6)
+            iters = total_iterations if total_iterations is not None else 1e9
+            name, self.lr0, self.momentum = ("SGD", 0.01, 0.9) if iters > 10000 else ("AdamW", lr_fit, 0.9)
+            a.warmup_bias_lr = 0.0
+        else:
+            self.lr0, self.momentum = a.lr0, a.momentum
+        self.opt_name = name
+        if name == "AdamW":
+            self.flat.m2 = torch.zeros_like(self.flat.m)
+        self.mse_acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.accumulate = 1
+        return self
+
+    # ---------------------------------------------------------------- batch
+    def preprocess_batch(self, batch):
+        """reference detect/train.py:70-111 (tensor part): clean_img, img (darkened), recovery_loss_batch."""
+        a = self.args
+        img = batch["img"]
+        if img.dtype != torch.uint8:
+            raise RuntimeError("preprocess_batch expects the dataloader's uint8 image tensor")
+        img = img.to(self.device, non_blocking=True).contiguous()
+        n = img.numel()
+        out = torch.empty(img.shape, dtype=torch.float32, device=self.device)
+        low, ded = bool(getattr(a, "lowlight_FLAG", False)), bool(getattr(a, "dedark_FLAG", False))
+        both = low and ded
+        clean = out if both else torch.empty_like(out)
+        self.mse_acc.zero_()
+        call("dy_preprocess_batch", ptr(img), ptr(out), None if both else ptr(clean), float(a.dark_param), int(low), int(ded),
+             ptr(self.mse_acc), n, stream())
+        batch["img"] = out
+        batch["clean_img"] = clean
+        batch["recovery_loss_batch"] = (self.mse_acc / n).float().reshape(())
+        return batch
+
+    # ---------------------------------------------------------------- step
+    def lr_factors(self, ni, nw, epoch, epochs):
+        """warm-up interpolation of trainer.py:318-327 + linear / cosine schedule (:255-259)."""
+        a = self.args
+        lf = ((1 - math.cos(epoch * math.pi / epochs)) / 2) * (a.lrf - 1) + 1 if a.cos_lr else (1 - epoch / epochs) * (1.0 - a.lrf) + a.lrf
+        lr = [self.lr0 * lf] * 3
+        mom = self.momentum
+        if ni <= nw:
+            xi = ni / max(nw, 1)
+            lr = [self.lr0 * lf * xi, self.lr0 * lf * xi, a.warmup_bias_lr + (self.lr0 * lf - a.warmup_bias_lr) * xi]
+            mom = a.warmup_momentum + (self.momentum - a.warmup_momentum) * xi
+        return lr, mom
+
+    def optimizer_step(self, lr, mom):
+        """clip_grad_norm_(10.0) + optimizer.step() + zero_grad() + ema.update() (trainer.py:459-467) in 2 kernels."""
+        f = self.flat
+        st = stream()
+        f.sumsq.zero_()
+        call("dy_sumsq", ptr(f.g), f.n, ptr(f.sumsq), st)
+        self.updates += 1
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000))                       # torch_utils.py:357
+        wd = self.args.weight_decay
+        if self.opt_name == "AdamW":
+            call("dy_adamw_step", ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.m2), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0,
+                 mom, 0.999, 1e-8, self.updates, d, ptr(f.sumsq), 10.0, 1.0, f.n, st)
+        else:
+            call("dy_sgd_step", ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0, mom, 1, d,
+                 ptr(f.sumsq), 10.0, 1.0, f.n, st)
+        if f.buf_ema is not None and f.buf_flat.numel():
+            call("dy_ema_lerp", ptr(f.buf_ema), ptr(f.buf_flat), d, f.buf_flat.numel(), st)
+        ops.bump_weights_epoch()
+
+    def train_step(self, batch, lr=None, mom=None):
+        """preprocess + forward + loss + backward (+ bucketed all-reduce) + optimizer/EMA. Returns (loss, loss_items)."""
+        batch = self.preprocess_batch(batch)
+        loss, items = self.model(batch)
+        loss.backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+        if lr is None:
+            lr, mom = [self.lr0] * 3, self.momentum
+        self.optimizer_step(lr, mom)
+        self.step_count += 1
+        return loss.detach(), items
+
+    def train(self, loader, epochs=None):
+        epochs = epochs or self.args.epochs
+        nb = len(loader)
+        nw = max(round(self.args.warmup_epochs * nb), 100) if self.args.warmup_epochs > 0 else -1
+        history = []
+        for epoch in range(epochs):
+            for i, batch in enumerate(loader):
+                ni = i + nb * epoch
+                lr, mom = self.lr_factors(ni, nw, epoch, epochs)
+                loss, items = self.train_step(batch, lr, mom)
+            history.append([float(v) for v in items])
+        return history

@@ -65,6 +65,9 @@ class _ModuleFn(torch.autograd.Function):
         if not isinstance(gins, (list, tuple)):
             gins = (gins,)
         assert not tape.stack, f"{type(module).__name__}: unbalanced tape"
+        cb = module.__dict__.get("_dy_after_backward")
+        if cb is not None:
+            cb()                 # data-parallel trainer: this layer's gradients are enqueued -> maybe launch its bucket
         pg = [tape.pgrads.get(p) for p in module._plist]
         return (None, None, *gins, *pg)
 

@@ -246,6 +246,8 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         stats = arena.alloc(2 * cout_pad, dev)
         d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
                        False, dtype)
+        _C.set_meta(kind="conv_fwd", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+                    bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         aff = torch.empty((4, cout_pad), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
         call("dy_bn_finalize", ptr(stats), B * Ho * Wo, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
@@ -253,6 +255,8 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
              cout_pad, stream())
         _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
         y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
+        _C.set_meta(kind="bn_act_fwd", dtype=str(dtype), flops=0.0,
+                    bytes=float(B * Ho * Wo * cout_pad * x.element_size() * (3 if residual is not None else 2)))
         call("dy_bn_act_fwd", ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), act, ptr(residual),
              ld_of(residual) if residual is not None else 0, ptr(y), ld_of(y), B * Ho * Wo, cout_pad, dt_id(dtype), stream())
         if ctx is not None:
@@ -269,6 +273,8 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         y = out if (out is not None and direct) else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         d = _conv_desc(x, wp, y, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, scale, shift, act, None, False,
                        dtype)
+        _C.set_meta(kind="conv_fwd", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+                    bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         if not direct:                  # eval-time residual: y_out = y + residual
             tgt = out if out is not None else y
@@ -322,6 +328,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     if ctx.has_bn:
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
         sums = arena.alloc(2 * cout_pad, dev)
+        _C.set_meta(kind="bn_act_bwd_reduce", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
         call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
         dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
@@ -330,6 +337,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         if not direct:
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
+        _C.set_meta(kind="bn_act_bwd_apply", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
         call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
         if not direct:
@@ -363,6 +371,8 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     # weight gradient
     if ctx.owner.requires_grad:
         dwp = torch.zeros(cout_pad * KH * KW * cin_pad, dtype=torch.float32, device=dev)
+        _C.set_meta(kind="conv_wgrad", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+                    bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size() + Cout * KH * KW * Cin * 4))
         call("dy_conv2d_wgrad", ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride,
              ctx.pad, ctx.dil, ptr(dwp), did, st)
         gd = _grad_dst(ctx.owner)
@@ -382,6 +392,8 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
             raise RuntimeError("conv_backward: dx_out view too narrow")
     d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
                    None, accumulate, dtype)
+    _C.set_meta(kind="conv_dgrad", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+                bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)
     if dx_out is not None:
         return dx_out

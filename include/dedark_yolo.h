@@ -187,12 +187,17 @@ int dy_preprocess_batch(const uint8_t* img, float* img_out, float* clean_out, fl
  * BaseTrainer.optimizer_step (U/engine/trainer.py:459-467): clip_grad_norm_(10.0) + SGD(nesterov) / AdamW step +
  * ModelEMA.update (U/utils/torch_utils.py:360-371) on flat f32 parameter ranges. */
 int dy_sumsq(const float* g, int64_t n, double* acc, void* stream);
-/* clip coefficient = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq != NULL; ema may be NULL */
-int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, float lr, float momentum, float weight_decay,
-                int nesterov, float ema_decay, const double* sumsq, float max_norm, int64_t n, void* stream);
-int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float ema_decay, const double* sumsq, float max_norm, int64_t n,
-                  void* stream);
+/* One flat buffer holds every trainable parameter; group_id[i] in {0,1,2} selects (lr, weight_decay) of the reference's three
+ * parameter groups (decayed weights / BN weights / biases; NULL = group 0).  g is multiplied by grad_scale and by the clip
+ * coefficient min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq != NULL; ema may be NULL. */
+int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1, float lr2,
+                float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay, const double* sumsq,
+                float max_norm, float grad_scale, int64_t n, void* stream);
+int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, const uint8_t* group_id, float lr0,
+                  float lr1, float lr2, float wd0, float wd1, float wd2, float beta1, float beta2, float eps, int step,
+                  float ema_decay, const double* sumsq, float max_norm, float grad_scale, int64_t n, void* stream);
+/* ema = decay*ema + (1-decay)*src (EMA of the BatchNorm running buffers) */
+int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream);
 int dy_frontend_init(void); /* uploads the gaussian taps (call once per process, outside graph capture) */
 
 #ifdef __cplusplus

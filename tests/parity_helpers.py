@@ -51,7 +51,7 @@ def build_models(yaml_name, scale, scale_def, seed, nc=20, device="cuda"):
     return model, (plan, save, sd)
 
 
-def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch.float32, with_oracle=True):
+def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch.float32, with_oracle=True, fp64=False):
     """One training step (forward + loss + backward) on the HIP path and on the oracle; returns scalars + grad errors."""
     import dedark_yolo_amd as dy
     from oracle import loss as oloss
@@ -81,16 +81,36 @@ def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch
         ol.backward()
         out["oracle_loss"] = float(ol)
         out["oracle_items"] = [float(v) for v in oi]
-        worst, worst_k = 0.0, None
+        ref64 = None
+        if fp64:      # conditioning probe: the same oracle in float64 tells how much fp32 rounding alone moves each gradient
+            sd64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone())
+                    for k, v in om.rng_fill(om.param_shapes(plan), seed).items()}
+            for k, v in sd64.items():
+                if v.is_floating_point():
+                    v.requires_grad_(v.ndim > 0 and ".dfl." not in k and "running_" not in k)
+            b64 = dict(batch)
+            b64["img"] = batch["img"].double()
+            m64 = om.forward(plan, save, sd64, b64["img"], True)
+            l64, _ = oloss.recovery_detection_loss(m64, b64, strides, 20, oloss.default_hyp())
+            l64.backward()
+            ref64 = {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.grad is not None}
+        errs = []
         for k, p in named.items():
             if p.grad is None or sd[k].grad is None:
                 continue
             g, r = p.grad.detach().float().cpu(), sd[k].grad
-            e = float((g - r).norm() / (r.norm() + 1e-12)) if float(r.norm()) > 1e-10 else float((g - r).norm())
-            if e > worst:
-                worst, worst_k = e, k
-        out["worst_grad_rel"] = worst
-        out["worst_grad_key"] = worst_k
+            tgt = ref64[k].float() if ref64 is not None and k in ref64 else r
+            den = float(tgt.norm())
+            e = float((g - tgt).norm()) / den if den > 1e-10 else float((g - tgt).norm())
+            eo = (float((r - tgt).norm()) / den if den > 1e-10 else float((r - tgt).norm())) if ref64 is not None else 0.0
+            errs.append((e, eo, k))
+        errs.sort(reverse=True)
+        out["worst_grad_rel"] = errs[0][0]
+        out["worst_grad_key"] = errs[0][2]
+        out["worst5"] = [(round(e, 5), round(eo, 5), k) for e, eo, k in errs[:5]]
+        out["median_grad_rel"] = errs[len(errs) // 2][0]
+        if ref64 is not None:
+            out["worst_excess_over_oracle32"] = max(e / max(eo, 1e-4) for e, eo, _ in errs)
         # running statistics after the step
         msd = model.state_dict()
         rs = 0.0

