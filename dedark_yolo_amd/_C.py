@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdedark_yolo.so")
 
 DY_F32, DY_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
+STATS_REPLICAS = 64          # DY_STATS_REPLICAS of include/dedark_yolo.h
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -31,7 +32,8 @@ _SIGS = {
     "dy_frontend_init": [],
     "dy_conv2d_fwd": [C.POINTER(ConvDesc), vp],
     "dy_conv2d_dgrad": [C.POINTER(ConvDesc), vp],
-    "dy_conv2d_wgrad": [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "dy_conv2d_wgrad": [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp,
+                        i32, vp],
     "dy_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "dy_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, vp],
     "dy_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp],

@@ -1,18 +1,29 @@
 // BatchNorm (training statistics) + activation, forward and backward, NHWC, vectorised 16 B per lane.
 // Replaces nn.BatchNorm2d + SiLU / LeakyReLU(0.1) + residual add of the reference (ultralytics/nn/modules/conv.py:49-51,
 // block.py:24-45,565; eps / momentum set at utils/torch_utils.py:263-265).  All kernels are HBM-bound streaming kernels.
+//
+// Thread mapping: a thread owns ONE 16-byte channel group for its whole life (per-channel constants live in registers) and
+// walks pixels with a grid stride, two pixels in flight per iteration; a wave covers 64 consecutive channel groups of one
+// pixel row (1 KiB contiguous when C >= 512 bf16) or several adjacent pixels for narrower tensors.
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
 namespace {
+
+constexpr int NT = 256;
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                                    float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double m = stats[c] / count;
-  double var = stats[C + c] / count - m * m;      // biased (normalisation)
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < DY_STATS_REPLICAS; ++r) {
+    s1 += stats[(long)r * 2 * C + c];
+    s2 += stats[(long)r * 2 * C + C + c];
+  }
+  double m = s1 / count;
+  double var = s2 / count - m * m;      // biased (normalisation)
   if (var < 0) var = 0;
   float invstd = (float)(1.0 / sqrt(var + (double)eps));
   float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -37,68 +48,114 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
   shift[c] = beta[c] - rm[c] * sc;
 }
 
-template <typename T>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ z, long z_ld, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, int act, const T* __restrict__ res, long res_ld,
-                                  T* __restrict__ y, long y_ld, long pixels, int C) {
-  constexpr int VE = DT<T>::VE;
+struct Map {           // thread -> (channel group, first pixel, pixel stride)
+  int c;               // first channel of the group
+  long first, step;
+  bool active;
+};
+
+template <int VE>
+__device__ inline Map make_map(int C, int cgb, int rows) {
+  Map m;
   const int CG = C / VE;
-  const long total = pixels * CG;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long px = i / CG;
-    int c = (int)(i - px * CG) * VE;
-    float v[VE], r[VE];
-    ldvec<T>(z + px * z_ld + c, v);
-    if (res) ldvec<T>(res + px * res_ld + c, r);
+  const int cg_local = threadIdx.x % cgb, prow = threadIdx.x / cgb;
+  const int cg = blockIdx.y * cgb + cg_local;
+  m.active = prow < rows && cg < CG;
+  m.c = cg * VE;
+  m.first = (long)blockIdx.x * rows + prow;
+  m.step = (long)gridDim.x * rows;
+  return m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z, long z_ld, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, const T* __restrict__ res,
+                                                         long res_ld, T* __restrict__ y, long y_ld, long pixels, int C, int cgb,
+                                                         int rows) {
+  constexpr int VE = DT<T>::VE;
+  const Map m = make_map<VE>(C, cgb, rows);
+  if (!m.active) return;
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    sc[e] = scale ? scale[m.c + e] : 1.f;
+    sh[e] = shift ? shift[m.c + e] : 0.f;
+  }
+  for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
+    const long pb = pa + m.step;
+    const bool hb = pb < pixels;
+    float va[VE], vb[VE], ra[VE], rb[VE];
+    ldvec<T>(z + pa * z_ld + m.c, va);
+    if (hb) ldvec<T>(z + pb * z_ld + m.c, vb);
+    if (res) {
+      ldvec<T>(res + pa * res_ld + m.c, ra);
+      if (hb) ldvec<T>(res + pb * res_ld + m.c, rb);
+    }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      float u = v[e] * (scale ? scale[c + e] : 1.f) + (shift ? shift[c + e] : 0.f);
-      float o = dy_act(act, u);
-      if (res) o += r[e];
-      v[e] = o;
+      float o = dy_act(act, va[e] * sc[e] + sh[e]);
+      va[e] = res ? o + ra[e] : o;
     }
-    stvec<T>(y + px * y_ld + c, v);
+    stvec<T>(y + pa * y_ld + m.c, va);
+    if (hb) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float o = dy_act(act, vb[e] * sc[e] + sh[e]);
+        vb[e] = res ? o + rb[e] : o;
+      }
+      stvec<T>(y + pb * y_ld + m.c, vb);
+    }
   }
 }
 
 // backward pass 1: per-channel sums of g and g*zhat
 template <typename T>
-__global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z, long z_ld,
-                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                         const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-                                         int has_bn, double* sums, long pixels, int C, int cgb, int rows_per_block) {
+__global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
+                                                                long z_ld, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int act, int has_bn,
+                                                                double* sums, long pixels, int C, int cgb, int rows) {
   constexpr int VE = DT<T>::VE;
   extern __shared__ float sred[];          // [2][cgb*VE]
-  const int CG = C / VE;
   const int tid = threadIdx.x;
-  const int cg_local = tid % cgb, prow = tid / cgb;
-  const int cg = blockIdx.y * cgb + cg_local;
-  const bool active = prow < rows_per_block && cg < CG;
-  for (int i = tid; i < 2 * cgb * VE; i += blockDim.x) sred[i] = 0.f;
+  const Map m = make_map<VE>(C, cgb, rows);
+  const int cg_local = tid % cgb;
+  for (int i = tid; i < 2 * cgb * VE; i += NT) sred[i] = 0.f;
   __syncthreads();
-  float s1[VE], s2[VE];
-#pragma unroll
-  for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (active) {
-    const int c = cg * VE;
-    float sc[VE], sh[VE], mu[VE], is[VE];
+  if (m.active) {
+    float sc[VE], sh[VE], mu[VE], is[VE], s1[VE], s2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      sc[e] = scale ? scale[c + e] : 1.f;
-      sh[e] = shift ? shift[c + e] : 0.f;
-      mu[e] = has_bn ? mean[c + e] : 0.f;
-      is[e] = has_bn ? invstd[c + e] : 0.f;
+      sc[e] = scale ? scale[m.c + e] : 1.f;
+      sh[e] = shift ? shift[m.c + e] : 0.f;
+      mu[e] = has_bn ? mean[m.c + e] : 0.f;
+      is[e] = has_bn ? invstd[m.c + e] : 0.f;
+      s1[e] = 0.f;
+      s2[e] = 0.f;
     }
-    for (long px = (long)blockIdx.x * rows_per_block + prow; px < pixels; px += (long)gridDim.x * rows_per_block) {
-      float g[VE], zz[VE];
-      ldvec<T>(dy + px * dy_ld + c, g);
-      ldvec<T>(z + px * z_ld + c, zz);
+    for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
+      const long pb = pa + m.step;
+      const bool hb = pb < pixels;
+      float ga[VE], za[VE], gb[VE], zb[VE];
+      ldvec<T>(dy + pa * dy_ld + m.c, ga);
+      ldvec<T>(z + pa * z_ld + m.c, za);
+      if (hb) {
+        ldvec<T>(dy + pb * dy_ld + m.c, gb);
+        ldvec<T>(z + pb * z_ld + m.c, zb);
+      }
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
-        float u = zz[e] * sc[e] + sh[e];
-        float ge = g[e] * dy_dact(act, u);
+        float ge = ga[e] * dy_dact(act, za[e] * sc[e] + sh[e]);
         s1[e] += ge;
-        s2[e] += ge * (zz[e] - mu[e]) * is[e];
+        s2[e] += ge * (za[e] - mu[e]) * is[e];
+      }
+      if (hb) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          float ge = gb[e] * dy_dact(act, zb[e] * sc[e] + sh[e]);
+          s1[e] += ge;
+          s2[e] += ge * (zb[e] - mu[e]) * is[e];
+        }
       }
     }
 #pragma unroll
@@ -108,7 +165,7 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, c
     }
   }
   __syncthreads();
-  for (int i = tid; i < cgb * VE; i += blockDim.x) {
+  for (int i = tid; i < cgb * VE; i += NT) {
     int c = blockIdx.y * cgb * VE + i;
     if (c < C) {
       atomic_add_f64(sums + c, (double)sred[i]);
@@ -118,46 +175,75 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, c
 }
 
 template <typename T>
-__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z, long z_ld,
-                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                        const float* __restrict__ gamma, int act, int has_bn,
-                                        const double* __restrict__ sums, T* __restrict__ dz, long dz_ld, float* dgamma,
-                                        float* dbeta, long pixels, int C) {
+__global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
+                                                               long z_ld, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               int act, int has_bn, const double* __restrict__ sums,
+                                                               T* __restrict__ dz, long dz_ld, float* dgamma, float* dbeta,
+                                                               long pixels, long count, int C, int cgb, int rows) {
   constexpr int VE = DT<T>::VE;
-  const int CG = C / VE;
-  const long total = pixels * CG;
-  const float invM = 1.f / (float)pixels;
   if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      if (dbeta) dbeta[c] = (float)sums[c];
-      if (dgamma && has_bn) dgamma[c] = (float)sums[C + c];
+    for (int i = threadIdx.x; i < cgb * VE; i += NT) {
+      int c = blockIdx.y * cgb * VE + i;
+      if (c < C) {
+        if (dbeta) dbeta[c] = (float)sums[c];
+        if (dgamma && has_bn) dgamma[c] = (float)sums[C + c];
+      }
     }
   }
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long px = i / CG;
-    int c = (int)(i - px * CG) * VE;
-    float g[VE], zz[VE];
-    ldvec<T>(dy + px * dy_ld + c, g);
-    ldvec<T>(z + px * z_ld + c, zz);
+  const Map m = make_map<VE>(C, cgb, rows);
+  if (!m.active) return;
+  const float invM = 1.f / (float)count;
+  float sc[VE], sh[VE], mu[VE], is[VE], k1[VE], ka[VE], kb[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    sc[e] = scale ? scale[m.c + e] : 1.f;
+    sh[e] = shift ? shift[m.c + e] : 0.f;
+    mu[e] = has_bn ? mean[m.c + e] : 0.f;
+    is[e] = has_bn ? invstd[m.c + e] : 0.f;
+    k1[e] = has_bn ? (gamma ? gamma[m.c + e] : 1.f) * is[e] : 1.f;
+    ka[e] = has_bn ? (float)sums[m.c + e] * invM : 0.f;
+    kb[e] = has_bn ? (float)sums[C + m.c + e] * invM : 0.f;
+  }
+  for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
+    const long pb = pa + m.step;
+    const bool hb = pb < pixels;
+    float ga[VE], za[VE], gb[VE], zb[VE];
+    ldvec<T>(dy + pa * dy_ld + m.c, ga);
+    ldvec<T>(z + pa * z_ld + m.c, za);
+    if (hb) {
+      ldvec<T>(dy + pb * dy_ld + m.c, gb);
+      ldvec<T>(z + pb * z_ld + m.c, zb);
+    }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      float u = zz[e] * (scale ? scale[c + e] : 1.f) + (shift ? shift[c + e] : 0.f);
-      float ge = g[e] * dy_dact(act, u);
-      if (has_bn) {
-        float zh = (zz[e] - mean[c + e]) * invstd[c + e];
-        float a = (float)sums[c + e] * invM, b = (float)sums[C + c + e] * invM;
-        ge = (gamma ? gamma[c + e] : 1.f) * invstd[c + e] * (ge - a - zh * b);
-      }
-      g[e] = ge;
+      float ge = ga[e] * dy_dact(act, za[e] * sc[e] + sh[e]);
+      ga[e] = k1[e] * (ge - ka[e] - (za[e] - mu[e]) * is[e] * kb[e]);
     }
-    stvec<T>(dz + px * dz_ld + c, g);
+    stvec<T>(dz + pa * dz_ld + m.c, ga);
+    if (hb) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float ge = gb[e] * dy_dact(act, zb[e] * sc[e] + sh[e]);
+        gb[e] = k1[e] * (ge - ka[e] - (zb[e] - mu[e]) * is[e] * kb[e]);
+      }
+      stvec<T>(dz + pb * dz_ld + m.c, gb);
+    }
   }
 }
 
-inline int ew_blocks(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+struct Geo { int cgb, rows; dim3 grid; };
+
+Geo geometry(long pixels, int C, int ve, int max_x) {
+  Geo g;
+  const int CG = C / ve;
+  g.cgb = CG < NT ? CG : NT;
+  g.rows = NT / g.cgb;
+  long want = (pixels + 2L * g.rows - 1) / (2L * g.rows);       // two pixels per thread per iteration
+  int gx = (int)(want > max_x ? max_x : (want < 1 ? 1 : want));
+  g.grid = dim3(gx, dy_cdiv(CG, g.cgb));
+  return g;
 }
 
 int check_view(const char* who, const void* p, long ld, int C, int dtype) {
@@ -195,15 +281,15 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   if (int e = check_view("dy_bn_act_fwd(z)", z, z_ld, C, dtype)) return e;
   if (int e = check_view("dy_bn_act_fwd(y)", y, y_ld, C, dtype)) return e;
   if (residual) if (int e = check_view("dy_bn_act_fwd(res)", residual, res_ld, C, dtype)) return e;
-  const int ve = dtype == DY_F32 ? 4 : 8;
-  const int blocks = ew_blocks(pixels * (C / ve));
+  if (pixels <= 0) return 0;
+  const Geo g = geometry(pixels, C, dtype == DY_F32 ? 4 : 8, 4096);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_fwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, z_ld, scale, shift, act, (const float*)residual, res_ld,
-                                                     (float*)y, y_ld, pixels, C);
+    bn_act_fwd_kernel<float><<<g.grid, NT, 0, st>>>((const float*)z, z_ld, scale, shift, act, (const float*)residual, res_ld,
+                                                    (float*)y, y_ld, pixels, C, g.cgb, g.rows);
   else
-    bn_act_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, z_ld, scale, shift, act, (const bf16_t*)residual,
-                                                      res_ld, (bf16_t*)y, y_ld, pixels, C);
+    bn_act_fwd_kernel<bf16_t><<<g.grid, NT, 0, st>>>((const bf16_t*)z, z_ld, scale, shift, act, (const bf16_t*)residual, res_ld,
+                                                     (bf16_t*)y, y_ld, pixels, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -214,21 +300,17 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   if (int e = check_view("dy_bn_act_bwd_reduce(dy)", dy, dy_ld, C, dtype)) return e;
   if (int e = check_view("dy_bn_act_bwd_reduce(z)", z, z_ld, C, dtype)) return e;
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_reduce: null stats");
+  if (pixels <= 0) return 0;
   const int ve = dtype == DY_F32 ? 4 : 8;
-  const int CG = C / ve;
-  const int cgb = CG < 256 ? CG : 256;
-  const int rows = 256 / cgb;
-  long want = (pixels + rows - 1) / rows;
-  int gx = (int)(want > 512 ? 512 : (want < 1 ? 1 : want));
-  dim3 grid(gx, dy_cdiv(CG, cgb));
-  size_t shm = 2 * (size_t)cgb * ve * sizeof(float);
+  const Geo g = geometry(pixels, C, ve, 1024);
+  size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_bwd_reduce_kernel<float><<<grid, 256, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
-                                                            invstd, act, has_bn, sums, pixels, C, cgb, rows);
+    bn_act_bwd_reduce_kernel<float><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
+                                                             invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
   else
-    bn_act_bwd_reduce_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                             mean, invstd, act, has_bn, sums, pixels, C, cgb, rows);
+    bn_act_bwd_reduce_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
+                                                              mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -241,17 +323,17 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   if (int e = check_view("dy_bn_act_bwd_apply(z)", z, z_ld, C, dtype)) return e;
   if (int e = check_view("dy_bn_act_bwd_apply(dz)", dz, dz_ld, C, dtype)) return e;
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_apply: null stats");
-  const int ve = dtype == DY_F32 ? 4 : 8;
-  const int blocks = ew_blocks(pixels * (C / ve));
+  // pixels == 0: only the parameter gradients (dgamma / dbeta) are written
+  const Geo g = geometry(pixels > 0 ? pixels : 1, C, dtype == DY_F32 ? 4 : 8, 4096);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_bwd_apply_kernel<float><<<blocks, 256, 0, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
-                                                           invstd, gamma, act, has_bn, sums, (float*)dz, dz_ld, dgamma, dbeta,
-                                                           pixels, C);
+    bn_act_bwd_apply_kernel<float><<<g.grid, NT, 0, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean, invstd,
+                                                          gamma, act, has_bn, sums, (float*)dz, dz_ld, dgamma, dbeta, pixels,
+                                                          pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
   else
-    bn_act_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                            mean, invstd, gamma, act, has_bn, sums, (bf16_t*)dz, dz_ld,
-                                                            dgamma, dbeta, pixels, C);
+    bn_act_bwd_apply_kernel<bf16_t><<<g.grid, NT, 0, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift, mean,
+                                                           invstd, gamma, act, has_bn, sums, (bf16_t*)dz, dz_ld, dgamma, dbeta,
+                                                           pixels, pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -500,11 +500,11 @@ extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, cons
   hipStream_t st = (hipStream_t)stream;
   const long BA = (long)m.B * m.A;
   if (n_max == 0) {          // tal.py:106-110
-    hipMemsetAsync(target_gt_idx, 0, BA * 4, st);
-    hipMemsetAsync(fg_mask, 0, BA, st);
-    hipMemsetAsync(norm, 0, BA * 4, st);
-    hipMemsetAsync(target_label, 0, BA * 4, st);
-    hipMemsetAsync(target_box, 0, BA * 16, st);
+    (void)hipMemsetAsync(target_gt_idx, 0, BA * 4, st);
+    (void)hipMemsetAsync(fg_mask, 0, BA, st);
+    (void)hipMemsetAsync(norm, 0, BA * 4, st);
+    (void)hipMemsetAsync(target_label, 0, BA * 4, st);
+    (void)hipMemsetAsync(target_box, 0, BA * 16, st);
     return 0;
   }
   DY_CHECK(work_f && work_i && work_b, "dy_tal_assign: null work buffers");
@@ -512,8 +512,8 @@ extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, cons
   float* align = work_f;
   float* overl = work_f + R;
   float* pos = work_f + 2 * R;       // [B*n_max*2]
-  hipMemsetAsync(work_b, 0, R, st);
-  hipMemsetAsync(work_f, 0, (2 * R + 2L * m.B * n_max) * sizeof(float), st);
+  (void)hipMemsetAsync(work_b, 0, R, st);
+  (void)hipMemsetAsync(work_f, 0, (2 * R + 2L * m.B * n_max) * sizeof(float), st);
   dim3 grid(n_max, m.B);
   if (d->dtype == DY_F32) tal_metrics_kernel<float><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
   else tal_metrics_kernel<bf16_t><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);

@@ -243,7 +243,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         ctx.cout, ctx.cout_pad, ctx.cin_pad, ctx.has_bn = Cout, cout_pad, cin_pad, has_bn
     if batch_stats:
         z = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
-        stats = arena.alloc(2 * cout_pad, dev)
+        stats = arena.alloc(2 * cout_pad * _C.STATS_REPLICAS, dev)
         d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
                        False, dtype)
         _C.set_meta(kind="conv_fwd", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
@@ -299,6 +299,18 @@ def _add_pgrad(tape, p, g):
         tape.pgrads[p] = tape.pgrads[p] + g
     else:
         tape.pgrads[p] = g
+
+
+_wg_scratch = {}
+
+
+def wgrad_scratch(device, elems=32 << 20):
+    """Reusable f32 workspace for the split-pixel partial tiles of dy_conv2d_wgrad (128 MiB; stream-ordered reuse)."""
+    t = _wg_scratch.get(device)
+    if t is None or t.numel() < elems:
+        t = torch.empty(elems, dtype=torch.float32, device=device)
+        _wg_scratch[device] = t
+    return t
 
 
 def _grad_dst(p):
@@ -370,14 +382,13 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
                     _add_pgrad(tape, ctx.bias, db[:Cout])
     # weight gradient
     if ctx.owner.requires_grad:
-        dwp = torch.zeros(cout_pad * KH * KW * cin_pad, dtype=torch.float32, device=dev)
+        gd = _grad_dst(ctx.owner)
+        gw = gd if gd is not None else torch.empty(ctx.weight.shape, dtype=torch.float32, device=dev)
+        scratch = wgrad_scratch(dev)
         _C.set_meta(kind="conv_wgrad", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size() + Cout * KH * KW * Cin * 4))
         call("dy_conv2d_wgrad", ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride,
-             ctx.pad, ctx.dil, ptr(dwp), did, st)
-        gd = _grad_dst(ctx.owner)
-        gw = gd if gd is not None else torch.empty(ctx.weight.shape, dtype=torch.float32, device=dev)
-        call("dy_unpack_wgrad", ptr(dwp), ptr(gw), Cout, Cin, cin_pad, KH, KW, st)
+             ctx.pad, ctx.dil, Cout, Cin, ptr(scratch), scratch.numel(), ptr(gw), did, st)
         if gd is None:
             _add_pgrad(tape, ctx.owner, gw.view(ctx.owner.shape))
     if not need_dx:

@@ -23,6 +23,7 @@ extern "C" {
 #define DY_ACT_NONE 0
 #define DY_ACT_SILU 1
 #define DY_ACT_LEAKY 2 /* LeakyReLU(0.1) */
+#define DY_STATS_REPLICAS 64 /* copies of the BN batch-statistics accumulators filled by dy_conv2d_fwd */
 
 const char* dy_last_error(void);
 int dy_version(void);
@@ -43,7 +44,8 @@ typedef struct {
   const float* scale; /* optional per-Cd affine applied to the accumulator: v = acc*scale + shift (NULL = 1) */
   const float* shift; /* optional (bias / folded BN shift) (NULL = 0) */
   int act;            /* DY_ACT_* applied after the affine */
-  double* stats;      /* optional [2*Cd] (sum, sum of squares) of the RAW accumulator over all pixels (BN batch stats) */
+  double* stats;      /* optional [DY_STATS_REPLICAS][2*Cd] zeroed accumulators: (sum, sum of squares) of the RAW conv
+                         output over all pixels, spread over replicas to avoid atomic contention (BN batch stats) */
   int accumulate;     /* 1: dst += result */
   int dtype;          /* DY_F32 | DY_BF16 (src, w, dst) */
 } dy_conv_desc;
@@ -53,10 +55,13 @@ int dy_conv2d_fwd(const dy_conv_desc* d, void* stream);
 /* data gradient: src = dz [N,Hs,Ws,Cs=Cout], w = transposed pack [Cd=Cin][KH][KW][Cs=Cout], dst = dx [N,Hd,Wd,Cd];
  * dx[n,h,w,:] = sum over taps with (h+pad-kh*dil) % stride == 0 of dz[n,(h+pad-kh*dil)/stride, ...,:] * w */
 int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream);
-/* weight gradient: dw[Cout][KH][KW][Cin] (f32, ACCUMULATED with atomics; zero it first) += sum_pixels dz^T * gather(x).
- * x view [N,Hi,Wi,Cin], dz view [N,Ho,Wo,Cout]. */
-int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin, const void* dz, int64_t dz_ld, int Ho,
-                    int Wo, int Cout, int KH, int KW, int stride, int pad, int dil, float* dw, int dtype, void* stream);
+/* weight gradient: g_oihw[Cout][Cin][KH][KW] (f32, overwritten) = sum_pixels dz^T * gather(x).
+ * x view [N,Hi,Wi,Cin_pad], dz view [N,Ho,Wo,Cout_pad] (zero-padded channels).  The pixel reduction is split over
+ * thread blocks that store partial tiles into `scratch` (any f32 workspace of scratch_elems floats, >= one tile set;
+ * more allows more splits); a second kernel sums the slabs in a fixed order (deterministic, no atomics) and writes OIHW. */
+int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, int64_t dz_ld, int Ho,
+                    int Wo, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
+                    int64_t scratch_elems, float* g_oihw, int dtype, void* stream);
 /* f32 OIHW [Cout][Cin][KH][KW] -> packed [Cout_pad][KH][KW][Cin_pad] (transposed=0) or [Cin_pad][KH][KW][Cout_pad]
  * (transposed=1) in `dtype`; padded input/output channels are written as zero. */
 int dy_pack_weight(const float* w_oihw, void* packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int KH, int KW,
@@ -67,7 +72,8 @@ int dy_unpack_wgrad(const float* dw_packed, float* g_oihw, int Cout, int Cin, in
 /* ------------------------------------------------------------------------------------ BatchNorm + activation
  * Replaces nn.BatchNorm2d (train: batch statistics, eps 1e-3, momentum 0.03, U/utils/torch_utils.py:263-265) followed by
  * SiLU / LeakyReLU(0.1) (conv.py:40,51; block.py:42) and the Bottleneck residual add (block.py:565). */
-/* stats[2C] (from dy_conv2d_fwd) -> scale/shift (y = z*scale + shift), saved mean/invstd, running buffers update. */
+/* stats[DY_STATS_REPLICAS][2C] (from dy_conv2d_fwd) -> scale/shift (y = z*scale + shift), saved mean/invstd, running buffers
+ * update. */
 int dy_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                    int C, void* stream);
