@@ -11,8 +11,16 @@
 // Pipeline: global -> registers prefetch of step s+1 overlaps the MFMAs of step s (register staging; single LDS buffer).
 // Block ids are remapped so that each XCD (private L2) owns a contiguous range of output tiles (3x3 halo rows and the
 // weight panel stay L2-resident).
+#include <stdlib.h>
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
+
+// pipelined wide-channel bf16 kernel (conv_v2.hip)
+bool dy_conv_v2_eligible(const dy_conv_desc* d);
+int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
+// band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
+bool dy_conv_v3_eligible(const dy_conv_desc* d);
+int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
 
 namespace {
 
@@ -37,6 +45,7 @@ struct ConvP {
   int Ktot;   // KH*KW*Cs
   int tiles_n;
   int nblk;
+  int ablate;   // DY_ABLATE env (diagnostics only): 1 skip global loads, 2 skip MFMA, 4 skip stores, 8 skip LDS restage
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -207,11 +216,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
-    if (more) {
+    if (more && !(p.ablate & 1)) {
       advance();
       load_step();
     }
-    mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
+    if (!(p.ablate & 2)) mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
+    if (more && (p.ablate & 8)) continue;
     __syncthreads();
     if (more) {
       store_step();
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
           float v = dy_act(p.act, a * sc + sf);
           T* o = dst + m * p.dst_ld + n;
           if (p.accumulate) v += DT<T>::ld(o);
-          DT<T>::st(o, v);
+          if (!(p.ablate & 4)) DT<T>::st(o, v);
         }
       }
     }
@@ -478,24 +488,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgP p) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_k,
                                                             int bm, int bn, int Cin, int Cin_pad, int KH, int KW, int Ktot,
                                                             float* __restrict__ g) {
-  extern __shared__ float row[];          // [Ktot]
+  // block = (one output channel, 32 consecutive k); 8 split-lanes per k walk the slabs with 8 loads in flight each
+  __shared__ float red[8][33];
   const int co = blockIdx.x;
   const int tile_c = co / bm, r = co - tile_c * bm;
-  for (int k = threadIdx.x; k < Ktot; k += blockDim.x) {
+  const int kl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int k = blockIdx.y * 32 + kl;
+  float a = 0.f;
+  if (k < Ktot) {
     const int tile_k = k / bn, c = k - tile_k * bn;
     const float* src = part + ((long)(tile_c * tiles_k + tile_k) * bm + r) * bn + c;
     const long sstride = (long)tiles * bm * bn;
-    float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += src[s * sstride];
-    row[k] = a;
+    int s = sl;
+    for (; s + 56 < splits; s += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(s + 8 * u) * sstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s < splits; s += 8) a += src[(long)s * sstride];
   }
+  red[sl][kl] = a;
   __syncthreads();
-  const int n = Cin * KH * KW;
-  float* o = g + (long)co * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    int kw = i % KW, t = i / KW;
-    int kh = t % KH, ci = t / KH;
-    o[i] = row[(kh * KW + kw) * Cin_pad + ci];
+  if (sl == 0 && k < Ktot) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += red[u][kl];
+    const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
+    if (ci < Cin) {
+      const int kh = tap / KW, kw = tap - kh * KW;
+      g[(((long)co * Cin + ci) * KH + kh) * KW + kw] = t;
+    }
   }
 }
 
@@ -545,6 +569,8 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st) {
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.Ktot = d->KH * d->KW * d->Cs;
+  static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
+  p.ablate = ablate;
   constexpr int BM = 128;
   const int tiles_m = dy_cdiv(p.M, BM);
   if (d->Cd <= 32) {
@@ -585,6 +611,8 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   const int ho = (d->Hs + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int wo = (d->Ws + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
+  if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
+  if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
   return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : launch_conv<bf16_t, 0>(d, st);
 }
@@ -596,6 +624,8 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   const int wo = (d->Wd + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   DY_CHECK(ho == d->Hs && wo == d->Ws, "dy_conv2d_dgrad: dz %dx%d does not match conv output %dx%d", d->Hs, d->Ws, ho, wo);
   DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
+  if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
+  if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;
   return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : launch_conv<bf16_t, 1>(d, st);
 }
@@ -637,8 +667,8 @@ int launch_wgrad(WgP p, float* scratch, long scratch_elems, float* g_oihw, int C
   else WG(128, 32, 4, 1);
 #undef WG
   DY_LAUNCH_CHECK();
-  wgrad_reduce_kernel<<<Cout_real, 256, p.Ktot * sizeof(float), st>>>(scratch, (int)splits, tiles, p.tiles_k, bm, bn, Cin_real,
-                                                                      p.Cin, p.KH, p.KW, p.Ktot, g_oihw);
+  wgrad_reduce_kernel<<<dim3(Cout_real, dy_cdiv(p.Ktot, 32)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_k, bm, bn,
+                                                                            Cin_real, p.Cin, p.KH, p.KW, p.Ktot, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -656,7 +686,6 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   DY_CHECK(((uintptr_t)x) % 16 == 0 && ((uintptr_t)dz) % 16 == 0, "dy_conv2d_wgrad: pointer not 16-byte aligned");
   const int ho = (Hi + 2 * pad - dil * (KH - 1) - 1) / stride + 1, wo = (Wi + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   DY_CHECK(ho == Ho && wo == Wo, "dy_conv2d_wgrad: dz %dx%d does not match conv output %dx%d", Ho, Wo, ho, wo);
-  DY_CHECK((long)KH * KW * Cin_pad * 4 <= 60000, "dy_conv2d_wgrad: K=%d too large for the reduce kernel", KH * KW * Cin_pad);
   WgP p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
   p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout_pad;

@@ -1,0 +1,375 @@
+// Pipelined implicit-GEMM convolution for the wide-channel bf16 layers (YOLOv8-L stages): forward and data-gradient.
+//
+// Measured on MI355X with tools/conv_bench: the register-staged kernel of conv.hip spends 45 % of its time outside both the
+// MFMA pipe and HBM (ds_write staging pass, two barriers per K-step, address VALU).  This kernel removes that pass:
+//   * A (gathered activations) and B (packed weights) tiles go global -> LDS directly (global_load_lds, 16 B per lane, the
+//     per-lane SOURCE address does the implicit-GEMM gather; padding taps read a zero page), no VGPR staging, no ds_write;
+//   * 3-stage LDS ring, ONE raw s_barrier per K-step, counted s_waitcnt vmcnt(N) so the next stage stays in flight across
+//     the barrier (never drained to 0 inside the loop);
+//   * 256 x BN block tile on 8 waves (4 x 2), K-step 64 bf16 = 128-byte LDS rows, XOR swizzle (16-byte slot ^ (row>>1)&7)
+//     applied on the source side (the DMA image is lane-linear) and on the ds_read_b128 side: conflict-free fragments;
+//   * v_mfma_f32_32x32x16_bf16, f32 accumulate; BatchNorm batch statistics from the accumulators (replicated f64 atomics).
+// Requirements (checked by the dispatcher): bf16, Cs % 64 == 0 (a K-step never straddles two taps), dense 16-byte aligned views.
+#include <stdlib.h>
+#include "dy_common.h"
+#include "../../include/dedark_yolo.h"
+
+namespace v2 {
+
+constexpr int BM = 256, BK = 64, NT = 512, NSTAGE = 3;
+constexpr int ROW = 128;                 // bytes per LDS row (64 bf16)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[16];
+__device__ unsigned long long g_stamps[16];       // diagnostics (DY_ABLATE & 32): s_memtime at phase boundaries, block 0 / wave 0
+
+__device__ inline void stamp(int ablate, int i) {
+  if ((ablate & 32) && blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    g_stamps[i] = t;
+  }
+}
+
+struct P {
+  const char* src;
+  long src_ld;
+  int N, Hs, Ws, Cs;
+  const char* w;
+  char* dst;
+  long dst_ld;
+  int Hd, Wd, Cd;
+  int KH, KW, stride, pad, dil;
+  const float* scale;
+  const float* shift;
+  int act;
+  double* stats;
+  int accumulate;
+  long M;
+  int Ktot;
+  int tiles_n, nblk;
+  int ablate;     // DY_ABLATE (diagnostics): 1 no loads after the prologue, 2 no MFMA, 4 no stores, 16 no LDS fragment reads
+};
+
+__device__ inline int xcd_remap(int bid, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(NT) void conv_kernel(P p) {
+  constexpr int WN = 2, WM = 4;
+  constexpr int TM = BM / WM / 32;          // 2
+  constexpr int TN = BN / WN / 32;          // 2 (BN=128) or 1 (BN=64)
+  constexpr int A_LD = BM * 8 / NT;         // glds per thread for A per stage (4)
+  constexpr int B_LD = BN * 8 / NT;         // 2 or 1
+  constexpr int STAGE = (BM + BN) * ROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stamp(p.ablate, 0);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- DMA bookkeeping: instruction j of this wave fills rows 8*(wave + 8j) .. +7 of the tile, lane -> (row, slot)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int chunk = slot ^ (((4 * wave) + (lane >> 4)) & 7);       // logical 16-byte chunk of the row this lane fetches
+  const char* a_base[A_LD];
+  int a_h[A_LD], a_w[A_LD];
+  bool a_ok[A_LD];
+  const long HWd = (long)p.Hd * p.Wd;
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    long m = m0 + 8 * (wave + 8 * j) + lrow;
+    a_ok[j] = m < p.M;
+    long mm = a_ok[j] ? m : 0;
+    int img = (int)(mm / HWd);
+    int rem = (int)(mm - (long)img * HWd);
+    int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    a_base[j] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + chunk * 8) * 2;
+    if (MODE == 0) {
+      a_h[j] = oh * p.stride - p.pad;
+      a_w[j] = ow * p.stride - p.pad;
+    } else {
+      a_h[j] = oh + p.pad;
+      a_w[j] = ow + p.pad;
+    }
+  }
+  const char* b_ptr[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    int n = n0 + 8 * (wave + 8 * j) + lrow;
+    b_ok[j] = n < p.Cd;
+    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.Ktot + chunk * 8) * 2;
+  }
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  int kh = 0, kw = 0, ci = 0;              // tap / channel offset of the NEXT stage to issue
+
+  auto issue = [&](int buf) {
+    char* stage = smem + buf * STAGE;
+    // tap geometry is uniform for the whole K-step (Cs % 64 == 0)
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int sh, sw;
+      bool ok = a_ok[j];
+      if (MODE == 0) {
+        sh = a_h[j] + kh * p.dil;
+        sw = a_w[j] + kw * p.dil;
+      } else {
+        int th = a_h[j] - kh * p.dil, tw = a_w[j] - kw * p.dil;
+        ok = ok && th >= 0 && tw >= 0;
+        if (p.stride == 1) {
+          sh = th;
+          sw = tw;
+        } else {
+          sh = th / p.stride;
+          sw = tw / p.stride;
+          ok = ok && (sh * p.stride == th) && (sw * p.stride == tw);
+        }
+      }
+      ok = ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws;
+      const char* g = ok ? a_base[j] + (((long)sh * p.Ws + sw) * p.src_ld + ci) * 2 : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const char* g = b_ok[j] ? b_ptr[j] : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + BM * ROW + (wave + 8 * j) * 1024), 16, 0, 0);
+      b_ptr[j] += BK * 2;
+    }
+    ci += BK;
+    if (ci >= p.Cs) {
+      ci = 0;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = p.Ktot / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  // fragment row byte offsets (swizzle key (row>>1)&7 is per row)
+  int a_off[TM], a_key[TM], b_off[TN], b_key[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int row = wm * (BM / WM) + i * 32 + fr;
+    a_off[i] = row * ROW;
+    a_key[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int row = wn * (BN / WN) + j * 32 + fr;
+    b_off[j] = BM * ROW + row * ROW;
+    b_key[j] = (row >> 1) & 7;
+  }
+
+  stamp(p.ablate, 1);
+  issue(0);
+  if (nsteps > 1) issue(1);
+  stamp(p.ablate, 2);
+  for (int s = 0; s < nsteps; ++s) {
+    if (s == 1) stamp(p.ablate, 3);
+    if (s == 9) stamp(p.ablate, 4);
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nsteps && !(p.ablate & 1)) issue((s + 2) % NSTAGE);
+    const char* stage = smem + (s % NSTAGE) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = 2 * kk + fh;
+      u32x4 af[TM], bf[TN];
+      if (p.ablate & 16) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = u32x4{(unsigned)s, 1u, 2u, 3u};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = u32x4{(unsigned)kk, 1u, 2u, 3u};
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(stage + a_off[i] + ((c ^ a_key[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(stage + b_off[j] + ((c ^ b_key[j]) << 4));
+      }
+      if (p.ablate & 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j]));
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+
+  stamp(p.ablate, 5);
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The accumulators go through LDS once ([BM][BN] bf16 image in the now idle ring) so that the HBM side is written with
+  // 16-byte vectors of 8 consecutive channels (the first version stored 2 bytes per lane and 64 addresses per lane: its
+  // epilogue cost as much as the whole K loop on the stage-3/4 shapes).
+  const int cl = lane & 31, hh = lane >> 5;
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  __builtin_amdgcn_s_barrier();                   // every wave is done reading the ring
+  bf16_t* ct = reinterpret_cast<bf16_t*>(smem);   // [BM][BN]
+  const int act = p.act;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / WN) + j * 32 + cl;
+    const int n = n0 + col;
+    const bool nok = n < p.Cd;
+    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+    const float sf = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = wm * (BM / WM) + i * 32 + 4 * hh;
+      const long mrem = p.M - (m0 + row0);       // rows with (r&3)+8*(r>>2) < mrem are real pixels
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float a = acc[i][j][r];
+        if (nok && dr < mrem) {
+          csum[j] += a;
+          csq[j] += a * a;
+        }
+        float v = a * sc + sf;
+        if (act == DY_ACT_SILU) v = v * dy_sigmoid(v);
+        else if (act == DY_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+        ct[(row0 + dr) * BN + col] = f32_to_bf16(v);
+      }
+    }
+  }
+  __syncthreads();
+  stamp(p.ablate, 6);
+  {
+    constexpr int VPR = BN / 8;                  // 16-byte vectors per tile row
+    constexpr int RPP = NT / VPR;                // rows per pass
+    const int vc = tid % VPR, vr = tid / VPR;
+    const int n = n0 + vc * 8;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(p.dst);
+    if (n < p.Cd && !(p.ablate & 4)) {
+      const bool full = n + 8 <= p.Cd;
+#pragma unroll 4
+      for (int row = vr; row < BM; row += RPP) {
+        const long m = m0 + row;
+        if (m >= p.M) break;
+        u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * BN + vc * 8);
+        bf16_t* o = dst + m * p.dst_ld + n;
+        if (full) {
+          if (p.accumulate) {
+            float x[8], y[8];
+            ldvec<bf16_t>(o, x);
+            ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            stvec<bf16_t>(o, x);
+          } else {
+            *reinterpret_cast<u32x4*>(o) = v;
+          }
+        } else {                                 // ragged channel tail (Cd not a multiple of 8 never happens for padded views)
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          for (int q = 0; q < 8 && n + q < p.Cd; ++q) o[q] = p.accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+        }
+      }
+    }
+  }
+  stamp(p.ablate, 7);
+  if (p.stats) {
+    __syncthreads();                              // the bf16 image has been consumed: reuse LDS for the column sums
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (hh == 0) {
+        int c = wn * (BN / WN) + j * 32 + cl;
+        red[(wm * BN + c) * 2] = s1;
+        red[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int n = n0 + tid;
+      if (n < p.Cd) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += red[(w * BN + tid) * 2];
+          s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
+        atomic_add_f64(st + n, (double)s1);
+        atomic_add_f64(st + p.Cd + n, (double)s2);
+      }
+    }
+  }
+}
+
+template <int BN, int MODE>
+int launch(P& p, hipStream_t st) {
+  constexpr int SHMEM = NSTAGE * (BM + BN) * ROW;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BN, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e != hipSuccess) {
+      dy_set_error("conv_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 3;
+    }
+    configured = true;
+  }
+  p.tiles_n = dy_cdiv(p.Cd, BN);
+  p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
+  conv_kernel<BN, MODE><<<p.nblk, NT, SHMEM, st>>>(p);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace v2
+
+// true when the pipelined kernel can take this problem (the dispatcher in conv.hip falls back to the generic kernel otherwise)
+extern "C" int dy_debug_conv_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(v2::g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+
+bool dy_conv_v2_eligible(const dy_conv_desc* d) {
+  static const bool off = getenv("DY_NO_CONV_V2") != nullptr;
+  if (off) return false;
+  const long M = (long)d->N * d->Hd * d->Wd;
+  return d->dtype == DY_BF16 && d->Cs % 64 == 0 && d->Cd >= 64 && M >= 2048 && (d->src_ld * 2) % 16 == 0;
+}
+
+int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
+  v2::P p;
+  p.src = (const char*)d->src; p.src_ld = d->src_ld; p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
+  p.w = (const char*)d->w; p.dst = (char*)d->dst; p.dst_ld = d->dst_ld; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
+  p.M = (long)d->N * d->Hd * d->Wd;
+  p.Ktot = d->KH * d->KW * d->Cs;
+  static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
+  p.ablate = ablate;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = d->Cd > 64;
+  if (mode == 0) return wide ? v2::launch<128, 0>(p, st) : v2::launch<64, 0>(p, st);
+  return wide ? v2::launch<128, 1>(p, st) : v2::launch<64, 1>(p, st);
+}

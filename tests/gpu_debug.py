@@ -119,5 +119,11 @@ if __name__ == "__main__":
         conv_case(dt, 1, 32, 8, 10, 9, 3, 1, 2, 2)
         conv_case(dt, 2, 256, 256, 8, 8, 3, 1, 1)
         conv_case(dt, 2, 8, 16, 33, 31, 5, 1, 2)
+        if dt == torch.bfloat16:      # shapes routed to the pipelined kernel (conv_v2.hip): M >= 2048, Cin % 64 == 0
+            conv_case(dt, 2, 64, 128, 40, 40, 3, 1, 1)
+            conv_case(dt, 3, 128, 64, 32, 32, 3, 2, 1)
+            conv_case(dt, 2, 256, 192, 48, 48, 1, 1, 0)
+            conv_case(dt, 1, 64, 64, 50, 47, 3, 1, 1)
+            conv_case(dt, 2, 192, 320, 24, 24, 3, 1, 1)
     for dt in (torch.float32, torch.bfloat16):
         bn_case(dt)

@@ -1,0 +1,97 @@
+// Standalone micro-benchmark of the implicit-GEMM conv kernels through the C-ABI (no torch): times fwd / dgrad / wgrad on
+// the YOLOv8-L stage shapes with hipEvents and prints TFLOP/s and the fraction of the dense bf16 MFMA peak.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp -Ldedark_yolo_amd/lib -ldedark_yolo -o gpurun_out/conv_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../include/dedark_yolo.h"
+extern "C" int dy_debug_conv_stamps(unsigned long long* out);
+extern "C" int dy_debug_conv3_stamps(unsigned long long* out);
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int B, Cin, Cout, H, W, k, s, p; };
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+  int iters = argc > 1 ? atoi(argv[1]) : 20;
+  int B = argc > 2 ? atoi(argv[2]) : 64;
+  std::vector<Shape> shapes = {
+      {"s3 3x3 256->256 @40", B, 256, 256, 40, 40, 3, 1, 1},  {"s2 3x3 128->128 @80", B, 128, 128, 80, 80, 3, 1, 1},
+      {"s1 3x3 64->64 @160", B, 64, 64, 160, 160, 3, 1, 1},   {"s4 3x3 512->512 @20", B, 512, 512, 20, 20, 3, 1, 1},
+      {"1x1 1280->512 @40", B, 1280, 512, 40, 40, 1, 1, 0},   {"1x1 256->256 @80", B, 256, 256, 80, 80, 1, 1, 0},
+      {"3x3s2 256->512 @80", B, 256, 512, 80, 80, 3, 2, 1},   {"3x3s2 64->128 @320", B, 64, 128, 320, 320, 3, 2, 1},
+  };
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float* scratch;
+  const long scratch_elems = 32L << 20;
+  CK(hipMalloc(&scratch, scratch_elems * 4));
+  for (auto& s : shapes) {
+    const int Ho = (s.H + 2 * s.p - s.k) / s.s + 1, Wo = (s.W + 2 * s.p - s.k) / s.s + 1;
+    const long nx = (long)s.B * s.H * s.W * s.Cin, ny = (long)s.B * Ho * Wo * s.Cout, nw = (long)s.Cout * s.k * s.k * s.Cin;
+    std::vector<unsigned short> hx(nx), hw(nw), hy(ny);
+    unsigned seed = 12345;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = f2bf(rnd());
+    for (auto& v : hw) v = f2bf(rnd() * 0.05f);
+    for (auto& v : hy) v = f2bf(rnd());
+    unsigned short *dx, *dw, *dwt, *dy, *dz;
+    float* gw;
+    double* stats;
+    CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dwt, nw * 2)); CK(hipMalloc(&dy, ny * 2));
+    CK(hipMalloc(&dz, nx * 2)); CK(hipMalloc(&gw, nw * 4)); CK(hipMalloc(&stats, 64 * 2 * s.Cout * 8));
+    CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dwt, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dy, hy.data(), ny * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(stats, 0, 64 * 2 * s.Cout * 8));
+    dy_conv_desc f = {};
+    f.src = dx; f.src_ld = s.Cin; f.N = s.B; f.Hs = s.H; f.Ws = s.W; f.Cs = s.Cin; f.w = dw; f.dst = dy; f.dst_ld = s.Cout;
+    f.Hd = Ho; f.Wd = Wo; f.Cd = s.Cout; f.KH = f.KW = s.k; f.stride = s.s; f.pad = s.p; f.dil = 1; f.stats = stats; f.dtype = DY_BF16;
+    dy_conv_desc g = {};
+    g.src = dy; g.src_ld = s.Cout; g.N = s.B; g.Hs = Ho; g.Ws = Wo; g.Cs = s.Cout; g.w = dwt; g.dst = dz; g.dst_ld = s.Cin;
+    g.Hd = s.H; g.Wd = s.W; g.Cd = s.Cin; g.KH = g.KW = s.k; g.stride = s.s; g.pad = s.p; g.dil = 1; g.dtype = DY_BF16;
+    const double flops = 2.0 * s.B * Ho * Wo * (double)s.Cout * s.k * s.k * s.Cin;
+    float ms[3];
+    for (int which = 0; which < 3; ++which) {
+      auto run = [&]() {
+        int rc = 0;
+        if (which == 0) rc = dy_conv2d_fwd(&f, st);
+        else if (which == 1) rc = dy_conv2d_dgrad(&g, st);
+        else rc = dy_conv2d_wgrad(dx, s.Cin, s.B, s.H, s.W, s.Cin, dy, s.Cout, Ho, Wo, s.Cout, s.k, s.k, s.s, s.p, 1, s.Cout, s.Cin,
+                                  scratch, scratch_elems, gw, DY_BF16, st);
+        if (rc) { printf("call failed: %s\n", dy_last_error()); exit(1); }
+      };
+      for (int i = 0; i < 3; ++i) run();
+      CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) run();
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms[which], e0, e1));
+      ms[which] /= iters;
+    }
+    if (getenv("DY_ABLATE") && (atoi(getenv("DY_ABLATE")) & 32)) {
+      unsigned long long t[16];
+      CK(hipDeviceSynchronize());
+      dy_conv2d_fwd(&f, st);
+      CK(hipDeviceSynchronize());
+      if (s.k == 3 && s.s == 1) dy_debug_conv3_stamps(t); else dy_debug_conv_stamps(t);
+      printf("   fwd block0 cycles: prologue %llu | issue01 %llu | step0 %llu | steps1-8 %llu (per step %llu) | steps9-end %llu | lds image %llu | stores %llu\n",
+             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], (t[4] - t[3]) / 8, t[5] - t[4], t[6] - t[5], t[7] - t[6]);
+    }
+    printf("%-22s B=%d GF=%7.1f | fwd %7.1f us %6.1f TF (%4.1f%%) | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF\n", s.name, s.B,
+           flops / 1e9, ms[0] * 1e3, flops / ms[0] / 1e9, flops / ms[0] / 1e9 / 25.0, ms[1] * 1e3, flops / ms[1] / 1e9, ms[2] * 1e3,
+           flops / ms[2] / 1e9);
+    fflush(stdout);
+    hipFree(dx); hipFree(dw); hipFree(dwt); hipFree(dy); hipFree(dz); hipFree(gw); hipFree(stats);
+  }
+  return 0;
+}
