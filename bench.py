@@ -52,23 +52,33 @@ def synth_batch(seed, B, S, nc, device):
                 gamma=float(g.uniform(5.0, 10.0)))
 
 
-def cpu_baseline(nc, S, seconds_budget=25.0):
+def split_model_name(name):
+    """'yolov8n-lowlight.yaml' -> ('yolov8-lowlight.yaml', 'n') (reference tasks.py:935 guess_model_scale)."""
+    import re
+    m = re.match(r"^(yolov8)([nsmlx])(.*\.yaml)$", os.path.basename(name))
+    return (m.group(1) + m.group(3), m.group(2)) if m else (os.path.basename(name), "n")
+
+
+def cpu_baseline(model_name, nc, S, seconds_budget=25.0):
     """The oracle (CPU port of the reference path, oracle/) doing the same training step in fp32 on the host cores.
-    Bounded sample: B=4 images per step, 2 warm-up steps, then steps until ~seconds_budget of CPU time."""
+    Bounded sample: a small batch per step, warm-up, then steps until ~seconds_budget of CPU time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import loss as oloss
     from oracle import model as om
     from util import load_yaml
-    threads = torch.get_num_threads()
-    cfg = load_yaml("yolov8-lowlight.yaml")
-    plan, save = om.build_plan(cfg, scale="n", nc=nc)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))          # the box's CPU share for one GPU
+    torch.set_num_threads(threads)
+    yaml_name, scale = split_model_name(model_name)
+    cfg = load_yaml(yaml_name)
+    plan, save = om.build_plan(cfg, scale=scale, nc=nc)
     sd = om.rng_fill(om.param_shapes(plan), 0)
     params = []
     for k, v in sd.items():
         if v.is_floating_point() and v.ndim > 0 and ".dfl." not in k and "running_" not in k:
             v.requires_grad_(True)
             params.append(v)
-    B = 4
+    big = scale in "lx" or scale == "m"
+    B, warm = (2, 1) if big else (4, 2)
     b = synth_batch(99, B, S, nc, "cpu")
     hyp = oloss.default_hyp()
 
@@ -84,7 +94,7 @@ def cpu_baseline(nc, S, seconds_budget=25.0):
                 p -= 0.01 * p.grad
                 p.grad = None
 
-    for _ in range(2):
+    for _ in range(warm):
         step()
     t0, n = time.perf_counter(), 0
     while True:
@@ -94,8 +104,8 @@ def cpu_baseline(nc, S, seconds_budget=25.0):
         if el > seconds_budget or n >= 40:
             break
     return dict(value=round(B * n / el, 3), unit="img/s", cores=threads, kind="port",
-                sample=f"oracle (CPU port of the reference path) fp32, YOLOv8n+lowlight_recovery 640x640, batch {B}, {n} timed steps "
-                       f"after 2 warm-up, fwd+loss+bwd+SGD, torch {torch.__version__} with {threads} threads")
+                sample=f"oracle (CPU port of the reference path) fp32, {model_name} {S}x{S}, batch {B}, {n} timed steps "
+                       f"after {warm} warm-up, fwd+loss+bwd+SGD, torch {torch.__version__} with {threads} threads")
 
 
 def kernel_profile(trainer, batches, steps=3):
@@ -119,6 +129,16 @@ def kernel_profile(trainer, batches, steps=3):
             a["bytes"] += meta["bytes"]
             a["meta_n"] += 1
     return agg, steps
+
+
+def workload_tag(args):
+    """Which BASELINE.json config the command line is (C2 = YOLOv8n + lowlight_recovery B=32, C3 = repo yolov8.yaml@L B=64)."""
+    key = (os.path.basename(args.model), args.imgsz, args.batch, args.dtype)
+    if key == ("yolov8n-lowlight.yaml", 640, 32, "bf16"):
+        return "BASELINE configs[1] (C2: YOLOv8n + lowlight_recovery front-end)"
+    if key == ("yolov8l.yaml", 640, 64, "bf16"):
+        return "BASELINE configs[2] (C3: repo yolov8.yaml@L = lowlight_recovery + ASFF neck)"
+    return "custom workload"
 
 
 def main():
@@ -184,7 +204,7 @@ def main():
     out = dict(metric="training img/s at 640x640", value=round(args.batch * world * args.steps / el, 2), unit="img/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1000 * el / args.steps, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(workload=f"BASELINE C2: {args.model} (YOLOv8n + lowlight_recovery front-end), {args.imgsz}x{args.imgsz}, "
+               config=dict(workload=f"{workload_tag(args)}: {args.model}, {args.imgsz}x{args.imgsz}, "
                                     f"{args.dtype}, batch {args.batch}/GPU, nc={nc}, gamma~U(5,10), full train step "
                                     "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, inputs resident in HBM",
                            global_batch=args.batch * world, parallelism=f"dp{world}"),
@@ -213,7 +233,7 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(nc, args.imgsz)
+        out["cpu_baseline"] = cpu_baseline(args.model, nc, args.imgsz)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

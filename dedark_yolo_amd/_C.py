@@ -65,6 +65,9 @@ _SIGS = {
     "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],
     "dy_loss_bwd": [C.POINTER(DetMaps), vp * 3, i64 * 3, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp],
     "dy_detect_decode": [C.POINTER(DetMaps), vp, vp],
+    "dy_nms_candidates": [vp, i32, i32, i32, f32, i32, vp, vp, i64, vp],
+    "dy_nms_sort": [vp, vp, vp, i32, i64, vp, vp, vp],
+    "dy_nms_greedy": [vp, vp, vp, i32, i32, i32, i64, C.c_double, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp],
     "dy_preprocess_batch": [vp, vp, vp, f32, i32, i32, vp, i64, vp],
     "dy_sumsq": [vp, i64, vp, vp],
     "dy_sgd_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],

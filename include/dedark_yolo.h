@@ -13,6 +13,7 @@
  */
 #ifndef DEDARK_YOLO_H
 #define DEDARK_YOLO_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -185,6 +186,27 @@ int dy_loss_bwd(const dy_det_maps* m, void* const dmap[3], const int64_t dmap_ld
                 const double* acc, const float* grad_out, float hyp_box, float hyp_cls, float hyp_dfl, void* stream);
 /* Detect eval decode (head.py:66-93): y[B, 4+nc, A] f32 = cat(xywh*stride, sigmoid(cls)) */
 int dy_detect_decode(const dy_det_maps* m, float* y, void* stream);
+/* ------------------------------------------------------------------------------------------------ NMS
+ * non_max_suppression (U/utils/ops.py:144-278; called from U/models/yolo/detect/val.py:62-70) for the whole batch.
+ * pred [B, 4+nc, A] f32 = Detect's eval output (xywh px + class scores).  Three stages:
+ *  dy_nms_candidates: keys[b, slot] = (~bits(score) << 32) | (anchor*nc + cls) for every candidate (score > conf_thres; every
+ *                     (anchor, cls) pair when multi_label && nc > 1 (ops.py:244-246), else the anchor's best class (:248-249));
+ *                     counts[b] = number of candidates (may exceed cap = slots per image; the excess is dropped).
+ *  dy_nms_sort:       per-image ascending key sort == stable descending-score order of the reference's candidate list.
+ *                     workspace == NULL: only *workspace_bytes is written (size query).
+ *  dy_nms_greedy:     first min(count, max_nms) candidates (ops.py:255-256), boxes + cls*max_wh unless agnostic (:258-259),
+ *                     greedy suppression IoU > iou_thres (torchvision.ops.nms semantics, :261), first max_det kept (:262).
+ *                     out [B, max_det, 6] = (x1,y1,x2,y2,conf,cls); keep_idx [B, max_det] = anchor*nc + cls of each kept row;
+ *                     out_counts[B].  boxes_ws: B*max_nms*4 floats (16-byte aligned), dead_ws: B*max_nms bytes.
+ * The wall-clock break of ops.py:274-276 is deliberately not reproduced. */
+int dy_nms_candidates(const float* pred, int B, int nc, int A, float conf_thres, int multi_label, uint64_t* keys, int* counts,
+                      int64_t cap, void* stream);
+int dy_nms_sort(const uint64_t* keys, uint64_t* keys_sorted, const int* counts, int B, int64_t cap, void* workspace,
+                size_t* workspace_bytes, void* stream);
+int dy_nms_greedy(const float* pred, const uint64_t* keys_sorted, const int* counts, int B, int nc, int A, int64_t cap,
+                  double iou_thres, int max_nms, int max_det, float max_wh, int agnostic, float* boxes_ws, uint8_t* dead_ws,
+                  float* out, int64_t* keep_idx, int* out_counts, void* stream);
+
 /* preprocess_batch tensor part (U/models/yolo/detect/train.py:70-111): u8 NCHW -> f32 /255 (^gamma), mse accumulators */
 int dy_preprocess_batch(const uint8_t* img, float* img_out, float* clean_out, float dark_param, int lowlight, int dedark,
                         double* mse_acc, int64_t n, void* stream);

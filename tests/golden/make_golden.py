@@ -353,6 +353,24 @@ def g_val():
     boxes = xyxy.clone()
     sc = uops.scale_boxes((640, 640), boxes.clone(), (480, 360))
     save("g6_val", xywh=xywh, xyxy=xyxy, back=back, scaled=sc)
+    # DetectionValidator._process_batch (greedy one-to-one matching at 10 IoU thresholds) + the pre-NMS candidate stage of
+    # non_max_suppression are pure torch/numpy; the NMS call itself needs torchvision (absent) and stays unpinned.
+    from types import SimpleNamespace
+    from ultralytics.models.yolo.detect.val import DetectionValidator
+    me = SimpleNamespace(iouv=torch.linspace(0.5, 0.95, 10))
+    nl, nd = 14, 60
+    c = g.uniform(60, 580, (nl, 2))
+    s = g.uniform(30, 160, (nl, 2))
+    lab_box = np.concatenate((c - s / 2, c + s / 2), 1)
+    lab_cls = g.integers(0, 3, (nl, 1)).astype(np.float64)
+    src = g.integers(0, nl, nd)
+    det_box = lab_box[src] + g.normal(0, 9, (nd, 4))
+    det_box[nd // 2:] += g.normal(0, 40, (nd - nd // 2, 4))
+    det_cls = np.where(g.random(nd) < 0.8, lab_cls[src, 0], g.integers(0, 3, nd))
+    det = T(np.concatenate((det_box, g.random((nd, 1)), det_cls[:, None]), 1).astype(np.float32))
+    lab = T(np.concatenate((lab_cls, lab_box), 1).astype(np.float32))
+    correct = DetectionValidator._process_batch(me, det, lab)
+    save("g6_match", det=det, lab=lab, correct=correct)
 
 
 if __name__ == "__main__":

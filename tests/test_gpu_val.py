@@ -1,0 +1,167 @@
+"""GPU parity tests of the validation side: batched HIP NMS against the oracle's restatement of
+non_max_suppression on identical prediction tensors (kept (anchor, class) indices bit-exact, rows bit-exact), and the
+validator's mAP against the oracle pipeline fed with the product's own predictions (|dmAP| <= 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from util import load_yaml, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic_pred(seed, B, nc, A, S=640.0, clusters=40, hot=0.02):
+    """xywh px + class scores: boxes clustered around a few centres (so that suppression really happens), a small fraction
+    of confident scores, the rest near zero."""
+    g = np.random.default_rng(seed)
+    cen = g.uniform(0.1 * S, 0.9 * S, (B, clusters, 2))
+    siz = g.uniform(0.05 * S, 0.3 * S, (B, clusters, 2))
+    which = g.integers(0, clusters, (B, A))
+    bi = np.arange(B)[:, None]
+    xy = cen[bi, which] + g.normal(0, 6.0, (B, A, 2))
+    wh = siz[bi, which] * np.exp(g.normal(0, 0.08, (B, A, 2)))
+    sc = g.random((B, A, nc)) * 0.05
+    m = g.random((B, A, nc)) < hot
+    sc = np.where(m, g.uniform(0.2, 0.99, (B, A, nc)), sc)
+    pred = np.concatenate((xy, wh, sc), 2).transpose(0, 2, 1)
+    return torch.from_numpy(np.ascontiguousarray(pred.astype(np.float32)))
+
+
+def _check_nms(pred, conf, iou, multi_label=True, agnostic=False, max_det=300, max_nms=30000):
+    from oracle import val as oval
+    from dedark_yolo_amd.utils.ops import nms_batched
+    want = oval.non_max_suppression(pred, conf, iou, multi_label=multi_label, max_det=max_det, max_nms=max_nms,
+                                    max_wh=0 if agnostic else 7680)
+    out, cnt, keep = nms_batched(pred.cuda(), conf, iou, multi_label, agnostic, max_det, max_nms, 7680, return_indices=True)
+    torch.cuda.synchronize()
+    out, cnt, keep = out.cpu(), cnt.cpu(), keep.cpu()
+    B, no, A = pred.shape
+    nc = no - 4
+    total = 0
+    for b in range(B):
+        w = want[b]
+        assert int(cnt[b]) == w.shape[0], f"image {b}: kept {int(cnt[b])} vs oracle {w.shape[0]}"
+        got = out[b, :w.shape[0]]
+        assert torch.equal(got, w), f"image {b}: kept rows differ"
+        # integer output: (anchor, class) of every kept row, in order
+        a = keep[b, :w.shape[0]] // nc
+        j = keep[b, :w.shape[0]] % nc
+        assert torch.equal(j.float(), w[:, 5])
+        assert torch.equal(pred[b, 4 + j, a], w[:, 4])
+        assert (keep[b, w.shape[0]:] == -1).all()
+        total += w.shape[0]
+    return total
+
+
+def test_nms_bit_exact_random():
+    pred = _synthetic_pred(1, 4, 20, 2100)
+    assert _check_nms(pred, 0.25, 0.7) > 50
+    assert _check_nms(pred, 0.25, 0.45) > 50
+    assert _check_nms(pred, 0.001, 0.7, max_det=300) == 4 * 300          # val-style threshold: far more candidates than max_det
+
+
+def test_nms_single_label_and_agnostic():
+    pred = _synthetic_pred(2, 3, 5, 1344, hot=0.05)
+    assert _check_nms(pred, 0.25, 0.6, multi_label=False) > 20
+    assert _check_nms(pred, 0.25, 0.6, agnostic=True) > 10
+    one = _synthetic_pred(3, 2, 1, 1344, hot=0.2)                         # nc == 1 turns multi_label off (ops.py:211)
+    assert _check_nms(one, 0.3, 0.5) > 5
+
+
+def test_nms_ties_empty_and_caps():
+    pred = _synthetic_pred(4, 3, 4, 800, hot=0.1)
+    pred[0, 4:] = 0.0                                                     # image without candidates
+    pred[1, 4:] = torch.round(pred[1, 4:] * 8) / 8                        # heavy score ties -> order by candidate index
+    pred[2, :4, 100:140] = pred[2, :4, 100:101]                           # identical boxes
+    assert _check_nms(pred, 0.25, 0.7) > 10
+    assert _check_nms(pred, 0.2, 0.7, max_det=7) <= 14                    # max_det truncation
+    # max_nms smaller than the candidate count: only exact when the cut does not fall inside a tie -> unique scores
+    p2 = _synthetic_pred(5, 2, 4, 800, hot=0.3)
+    assert _check_nms(p2, 0.25, 0.7, max_nms=200) > 10
+
+
+def test_nms_full_size_batch():
+    """BASELINE shapes: B=32, nc=20, A=8400 -- checked through size-independent properties (sorted scores, no surviving
+    pair above the IoU threshold within a class, every survivor above conf)."""
+    from dedark_yolo_amd.utils.ops import nms_batched
+    from oracle import val as oval
+    pred = _synthetic_pred(6, 32, 20, 8400)
+    out, cnt = nms_batched(pred.cuda(), 0.25, 0.7, True, False, 300, 30000, 7680)
+    out, cnt = out.cpu(), cnt.cpu()
+    assert int(cnt.min()) > 0 and int(cnt.max()) <= 300
+    for b in range(32):
+        d = out[b, :int(cnt[b])]
+        assert (d[:, 4] > 0.25).all() and (d[1:, 4] <= d[:-1, 4]).all()
+        iou = oval.box_iou(d[:, :4], d[:, :4])
+        same = d[:, 5:6] == d[:, 5]
+        iou = torch.triu(iou * same, diagonal=1)
+        assert float(iou.max()) <= 0.7 + 5e-3       # suppression runs on class-offset f32 boxes (ops.py:259): 1/64 px grid at cls 19
+    # first image against the oracle exactly
+    w = oval.non_max_suppression(pred[:1], 0.25, 0.7)[0]
+    assert torch.equal(out[0, :w.shape[0]], w)
+
+
+def test_validator_map_vs_oracle_on_product_predictions():
+    """model (eval) -> Detect decode -> HIP NMS -> matching -> AP through the product validator, against the oracle's NMS +
+    matching + AP on the SAME prediction tensor; then the eval forward itself against the oracle's forward."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd.engine.trainer import get_cfg
+    from dedark_yolo_amd.engine.validator import DetectionValidator
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from oracle import model as om
+    from oracle import val as oval
+    from parity_helpers import load_sd
+    dy.set_compute_dtype(torch.float32)
+    nc, S, B = 20, 128, 6
+    cfgd = load_yaml("yolov8-lowlight.yaml")
+    cfgd["scales"]["t"] = [0.33, 0.125, 1024]
+    cfgd["scale"] = "t"
+    model = DetectionModel(cfgd, nc=nc)
+    plan, save = om.build_plan(cfgd, scale="t", nc=nc)
+    sd = om.rng_fill(om.param_shapes(plan), 11)
+    # confident heads: bias the class logits up so that NMS has something to do
+    for k in sd:
+        if ".cv3." in k and k.endswith("2.bias"):
+            sd[k] = sd[k] + 4.0
+    load_sd(model, sd)
+    model = model.cuda().eval()
+    g = np.random.default_rng(5)
+    img = torch.from_numpy((g.random((B, 3, S, S)) * 255).astype(np.uint8))
+    bi, cls, bb = [], [], []
+    for b in range(B):
+        for _ in range(3):
+            bi.append(b)
+            cls.append(int(g.integers(0, nc)))
+            cx, cy, w, h = g.uniform(0.3, 0.7), g.uniform(0.3, 0.7), g.uniform(0.1, 0.5), g.uniform(0.1, 0.5)
+            bb.append([cx, cy, w, h])
+    batch = dict(img=img, batch_idx=torch.tensor(bi, dtype=torch.float32), cls=torch.tensor(cls, dtype=torch.float32).view(-1, 1),
+                 bboxes=torch.tensor(bb, dtype=torch.float32), ori_shape=[(S, S)] * B)
+    v = DetectionValidator(get_cfg(dict(conf=0.25, iou=0.7)))
+    got = v(model, [batch])
+    # oracle pipeline on the product's predictions
+    with torch.no_grad():
+        x = (img.float() / 255).cuda()
+        y = model(x)[0].float().cpu()
+        y_or = om.forward(plan, save, sd, img.float() / 255, False)[0]
+    assert float((y - y_or).abs().max()) < 2e-3 * max(1.0, float(y_or.abs().max())), "eval forward vs oracle"
+    dets = oval.non_max_suppression(y, 0.25, 0.7)
+    stats = []
+    iouv = torch.linspace(0.5, 0.95, 10)
+    for si, d in enumerate(dets):
+        idx = batch["batch_idx"] == si
+        c, bx = batch["cls"][idx], batch["bboxes"][idx]
+        tbox = oval.xywh2xyxy(bx) * torch.tensor((S, S, S, S), dtype=torch.float32)
+        if d.shape[0] == 0:
+            stats.append((torch.zeros(0, 10, dtype=torch.bool), torch.zeros(0), torch.zeros(0), c.squeeze(-1)))
+            continue
+        dn = d.clone()
+        oval.scale_boxes((S, S), dn[:, :4], (S, S))
+        oval.scale_boxes((S, S), tbox, (S, S))
+        stats.append((oval.match_predictions(dn, torch.cat((c, tbox), 1), iouv), d[:, 4], d[:, 5], c.squeeze(-1)))
+    tp, conf, pcls, tcls = [torch.cat(z, 0).numpy() for z in zip(*stats)]
+    assert tp.shape[0] > 20, "test is vacuous without detections"
+    r = oval.ap_per_class(tp, conf, pcls, tcls)
+    want50, want = r["ap"][:, 0].mean(), r["ap"].mean()
+    assert abs(got["metrics/mAP50(B)"] - want50) <= 1e-4 and abs(got["metrics/mAP50-95(B)"] - want) <= 1e-4
+    assert abs(got["metrics/precision(B)"] - r["p"].mean()) <= 1e-4 and abs(got["metrics/recall(B)"] - r["r"].mean()) <= 1e-4
+    assert abs(got["fitness"] - oval.fitness(r["ap"])) <= 1e-4

@@ -116,3 +116,36 @@ def test_yaml_loader_and_scale_guess():
     assert guess_model_scale("yolov8n-lowlight.yaml") == "n"
     with pytest.raises(FileNotFoundError):
         yaml_model_load("yolov9q.yaml")
+
+
+# ---------------------------------------------------------------------------------------------- validation host logic
+def test_product_metrics_match_reference_goldens():
+    """utils/metrics.py + engine/validator.match_predictions + utils/ops box helpers against vectors captured from the
+    reference (g5_ap, g5_small, g6_val, g6_match) and against the oracle."""
+    import numpy as np
+    from util import close, gold
+    from dedark_yolo_amd.engine.validator import match_predictions
+    from dedark_yolo_amd.utils import metrics as M
+    from dedark_yolo_amd.utils import ops as O
+    g = gold("g5_ap")
+    tp, fp, p, r, f1, ap, uc = M.ap_per_class(g["tp"].numpy().astype(bool), g["conf"].numpy(), g["pred_cls"].numpy(), g["target_cls"].numpy())
+    close(ap, g["ap"], 1e-9, 1e-12, "ap")
+    close(p, g["p"], 1e-9, 1e-12, "p")
+    close(r, g["r"], 1e-9, 1e-12, "r")
+    close(f1, g["f1"], 1e-9, 1e-12, "f1")
+    assert np.array_equal(tp, g["tpc"].numpy()) and np.array_equal(fp, g["fpc"].numpy()) and np.array_equal(uc, g["unique"].numpy())
+    ka3 = M.compute_ap(np.array([.1, .2, .2, .4, .5, .5, .8]), np.array([1, 1, .67, .75, .8, .67, .6]))[0]      # SURVEY KA3
+    assert abs(ka3 - 0.68885) < 1e-9
+    dm = M.DetMetrics(names={i: str(i) for i in range(4)})
+    dm.process(g["tp"].numpy().astype(bool), g["conf"].numpy(), g["pred_cls"].numpy(), g["target_cls"].numpy())
+    rd = dm.results_dict
+    assert abs(rd["metrics/mAP50(B)"] - g["ap"].numpy()[:, 0].mean()) < 1e-12
+    assert abs(rd["fitness"] - (0.1 * g["ap"].numpy()[:, 0].mean() + 0.9 * g["ap"].numpy().mean())) < 1e-12
+    g = gold("g6_val")
+    close(O.xywh2xyxy(g["xywh"]), g["xyxy"], 0, 0, "xywh2xyxy")
+    close(O.xyxy2xywh(g["xyxy"]), g["back"], 0, 0, "xyxy2xywh")
+    close(O.scale_boxes((640, 640), g["xyxy"].clone(), (480, 360)), g["scaled"], 0, 1e-6, "scale_boxes")
+    g = gold("g6_match")
+    assert torch.equal(match_predictions(g["det"], g["lab"], torch.linspace(0.5, 0.95, 10)), g["correct"].bool())
+    s = gold("g5_small")
+    close(M.box_iou(s["b1"][:8], s["b2"][:12]), s["pairwise"], 0, 1e-7, "box_iou")

@@ -244,3 +244,10 @@ def test_nms_unpinned_semantics():
     scores = torch.tensor([0.9, 0.8, 0.7, 0.95])
     assert oval.nms(boxes, scores, 0.5).tolist() == [3, 2]
     assert oval.nms(boxes, scores, 0.99).tolist() == [3, 0, 1, 2]
+
+
+def test_match_predictions_golden():
+    """DetectionValidator._process_batch (val.py:151-174) captured from the reference."""
+    g = gold("g6_match")
+    got = oval.match_predictions(g["det"], g["lab"], torch.linspace(0.5, 0.95, 10))
+    assert torch.equal(got, g["correct"].bool())
