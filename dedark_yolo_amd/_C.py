@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdedark_yolo.so")
 DY_F32, DY_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
 STATS_REPLICAS = 64          # DY_STATS_REPLICAS of include/dedark_yolo.h
+BN_BWD_REPLICAS = 8          # DY_BN_BWD_REPLICAS
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -19,7 +20,13 @@ class ConvDesc(C.Structure):
     _fields_ = [("src", vp), ("src_ld", i64), ("N", i32), ("Hs", i32), ("Ws", i32), ("Cs", i32), ("w", vp), ("dst", vp),
                 ("dst_ld", i64), ("Hd", i32), ("Wd", i32), ("Cd", i32), ("KH", i32), ("KW", i32), ("stride", i32),
                 ("pad", i32), ("dil", i32), ("scale", vp), ("shift", vp), ("act", i32), ("stats", vp), ("accumulate", i32),
-                ("dtype", i32)]
+                ("dtype", i32), ("dst_row_stride", i64), ("dst_img_stride", i64), ("KHf", i32), ("KWf", i32), ("kh0", i32),
+                ("kh_step", i32), ("kw0", i32), ("kw_step", i32)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("w", vp), ("packed", vp), ("Cout", i32), ("Cout_pad", i32), ("Cin", i32), ("Cin_pad", i32), ("KH", i32),
+                ("KW", i32), ("transposed", i32), ("dtype", i32), ("first_block", i64)]
 
 
 class DetMaps(C.Structure):
@@ -35,6 +42,8 @@ _SIGS = {
     "dy_conv2d_wgrad": [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp,
                         i32, vp],
     "dy_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "dy_pack_item_blocks": [i32, i32, i32, i32],
+    "dy_pack_weights_multi": [vp, i32, i64, vp],
     "dy_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, vp],
     "dy_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp],
     "dy_bn_fold_eval": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
@@ -91,7 +100,7 @@ def lib():
         for name, sig in _SIGS.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
             fn.argtypes = sig
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name == "dy_pack_item_blocks" else C.c_int
         _lib = L
     return _lib
 

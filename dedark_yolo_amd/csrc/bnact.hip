@@ -12,16 +12,24 @@ namespace {
 
 constexpr int NT = 256;
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
-                                   float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: lane r sums replica r, then a wave reduction (the old one-thread-per-channel loop over the 64
+// replicas was a chain of 128 dependent-latency loads: 10 us for a 64-channel layer)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                           float momentum, float eps, float* scale, float* shift, float* mean_out,
+                                                           float* invstd_out, int C) {
+  static_assert(DY_STATS_REPLICAS == 64, "one replica per lane");
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < DY_STATS_REPLICAS; ++r) {
-    s1 += stats[(long)r * 2 * C + c];
-    s2 += stats[(long)r * 2 * C + C + c];
+  double s1 = stats[(long)lane * 2 * C + c];
+  double s2 = stats[(long)lane * 2 * C + C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
   }
+  if (lane != 0) return;
   double m = s1 / count;
   double var = s2 / count - m * m;      // biased (normalisation)
   if (var < 0) var = 0;
@@ -48,8 +56,25 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// v_exp_f32 / v_rcp_f32 based sigmoid (about 1e-6 relative error): the IEEE expf + division sequence made the SiLU
+// kernels ALU-bound (4.1 TB/s against 5.9 TB/s for the LeakyReLU variant of the same kernel).
+__device__ inline float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ inline float act_f(int act, float u) {
+  if (act == DY_ACT_SILU) return u * fast_sigmoid(u);
+  if (act == DY_ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+  return u;
+}
+__device__ inline float dact_f(int act, float u) {
+  if (act == DY_ACT_SILU) {
+    const float s = fast_sigmoid(u);
+    return s * (1.0f + u * (1.0f - s));
+  }
+  if (act == DY_ACT_LEAKY) return u > 0.f ? 1.0f : 0.1f;
+  return 1.0f;
+}
+
 struct Map {           // thread -> (channel group, first pixel, pixel stride)
-  int c;               // first channel of the group
+  int c, cl;           // first channel of the group (global / within the block's channel range)
   long first, step;
   bool active;
 };
@@ -62,48 +87,58 @@ __device__ inline Map make_map(int C, int cgb, int rows) {
   const int cg = blockIdx.y * cgb + cg_local;
   m.active = prow < rows && cg < CG;
   m.c = cg * VE;
+  m.cl = cg_local * VE;
   m.first = (long)blockIdx.x * rows + prow;
   m.step = (long)gridDim.x * rows;
   return m;
 }
 
+constexpr int UN = 4;   // pixels in flight per thread
+
+// Per-channel constants are staged once per block in LDS (coalesced loads by the first threads) and copied to registers.
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z, long z_ld, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, const T* __restrict__ res,
                                                          long res_ld, T* __restrict__ y, long y_ld, long pixels, int C, int cgb,
                                                          int rows) {
   constexpr int VE = DT<T>::VE;
+  extern __shared__ float lds[];               // [2][nch]
+  const int nch = cgb * VE, c0 = blockIdx.y * nch;
+  for (int i = threadIdx.x; i < nch; i += NT) {
+    const int c = c0 + i;
+    lds[i] = (scale && c < C) ? scale[c] : 1.f;
+    lds[nch + i] = (shift && c < C) ? shift[c] : 0.f;
+  }
+  __syncthreads();
   const Map m = make_map<VE>(C, cgb, rows);
   if (!m.active) return;
   float sc[VE], sh[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    sc[e] = scale ? scale[m.c + e] : 1.f;
-    sh[e] = shift ? shift[m.c + e] : 0.f;
+    sc[e] = lds[m.cl + e];
+    sh[e] = lds[nch + m.cl + e];
   }
-  for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
-    const long pb = pa + m.step;
-    const bool hb = pb < pixels;
-    float va[VE], vb[VE], ra[VE], rb[VE];
-    ldvec<T>(z + pa * z_ld + m.c, va);
-    if (hb) ldvec<T>(z + pb * z_ld + m.c, vb);
-    if (res) {
-      ldvec<T>(res + pa * res_ld + m.c, ra);
-      if (hb) ldvec<T>(res + pb * res_ld + m.c, rb);
-    }
+  for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
+    float v[UN][VE], r[UN][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float o = dy_act(act, va[e] * sc[e] + sh[e]);
-      va[e] = res ? o + ra[e] : o;
-    }
-    stvec<T>(y + pa * y_ld + m.c, va);
-    if (hb) {
-#pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        float o = dy_act(act, vb[e] * sc[e] + sh[e]);
-        vb[e] = res ? o + rb[e] : o;
+    for (int k = 0; k < UN; ++k) {
+      const long p = p0 + k * m.step;
+      if (p < pixels) {
+        ldvec<T>(z + p * z_ld + m.c, v[k]);
+        if (res) ldvec<T>(res + p * res_ld + m.c, r[k]);
       }
-      stvec<T>(y + pb * y_ld + m.c, vb);
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const long p = p0 + k * m.step;
+      if (p < pixels) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float o = act_f(act, v[k][e] * sc[e] + sh[e]);
+          v[k][e] = res ? o + r[k][e] : o;
+        }
+        stvec<T>(y + p * y_ld + m.c, v[k]);
+      }
     }
   }
 }
@@ -116,64 +151,74 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
                                                                 const float* __restrict__ invstd, int act, int has_bn,
                                                                 double* sums, long pixels, int C, int cgb, int rows) {
   constexpr int VE = DT<T>::VE;
-  extern __shared__ float sred[];          // [2][cgb*VE]
+  extern __shared__ float lds[];               // constants [4][nch], then accumulators [2][nch]
   const int tid = threadIdx.x;
-  const Map m = make_map<VE>(C, cgb, rows);
-  const int cg_local = tid % cgb;
-  for (int i = tid; i < 2 * cgb * VE; i += NT) sred[i] = 0.f;
+  const int nch = cgb * VE, c0 = blockIdx.y * nch;
+  float* sred = lds + 4 * nch;
+  for (int i = tid; i < nch; i += NT) {
+    const int c = c0 + i;
+    const bool ok = c < C;
+    lds[i] = (scale && ok) ? scale[c] : 1.f;
+    lds[nch + i] = (shift && ok) ? shift[c] : 0.f;
+    lds[2 * nch + i] = (has_bn && ok) ? mean[c] : 0.f;
+    lds[3 * nch + i] = (has_bn && ok) ? invstd[c] : 0.f;
+    sred[i] = 0.f;
+    sred[nch + i] = 0.f;
+  }
   __syncthreads();
+  const Map m = make_map<VE>(C, cgb, rows);
   if (m.active) {
     float sc[VE], sh[VE], mu[VE], is[VE], s1[VE], s2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      sc[e] = scale ? scale[m.c + e] : 1.f;
-      sh[e] = shift ? shift[m.c + e] : 0.f;
-      mu[e] = has_bn ? mean[m.c + e] : 0.f;
-      is[e] = has_bn ? invstd[m.c + e] : 0.f;
+      sc[e] = lds[m.cl + e];
+      sh[e] = lds[nch + m.cl + e];
+      mu[e] = lds[2 * nch + m.cl + e];
+      is[e] = lds[3 * nch + m.cl + e];
       s1[e] = 0.f;
       s2[e] = 0.f;
     }
-    for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
-      const long pb = pa + m.step;
-      const bool hb = pb < pixels;
-      float ga[VE], za[VE], gb[VE], zb[VE];
-      ldvec<T>(dy + pa * dy_ld + m.c, ga);
-      ldvec<T>(z + pa * z_ld + m.c, za);
-      if (hb) {
-        ldvec<T>(dy + pb * dy_ld + m.c, gb);
-        ldvec<T>(z + pb * z_ld + m.c, zb);
+    for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
+      float g[UN][VE], zz[UN][VE];
+#pragma unroll
+      for (int k = 0; k < UN; ++k) {
+        const long p = p0 + k * m.step;
+        if (p < pixels) {
+          ldvec<T>(dy + p * dy_ld + m.c, g[k]);
+          ldvec<T>(z + p * z_ld + m.c, zz[k]);
+        }
       }
 #pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        float ge = ga[e] * dy_dact(act, za[e] * sc[e] + sh[e]);
-        s1[e] += ge;
-        s2[e] += ge * (za[e] - mu[e]) * is[e];
-      }
-      if (hb) {
+      for (int k = 0; k < UN; ++k) {
+        const long p = p0 + k * m.step;
+        if (p < pixels) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          float ge = gb[e] * dy_dact(act, zb[e] * sc[e] + sh[e]);
-          s1[e] += ge;
-          s2[e] += ge * (zb[e] - mu[e]) * is[e];
+          for (int e = 0; e < VE; ++e) {
+            const float ge = g[k][e] * dact_f(act, zz[k][e] * sc[e] + sh[e]);
+            s1[e] += ge;
+            s2[e] += ge * ((zz[k][e] - mu[e]) * is[e]);
+          }
         }
       }
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      atomicAdd(&sred[cg_local * VE + e], s1[e]);
-      if (has_bn) atomicAdd(&sred[cgb * VE + cg_local * VE + e], s2[e]);
+      atomicAdd(&sred[m.cl + e], s1[e]);
+      if (has_bn) atomicAdd(&sred[nch + m.cl + e], s2[e]);
     }
   }
   __syncthreads();
-  for (int i = tid; i < cgb * VE; i += NT) {
-    int c = blockIdx.y * cgb * VE + i;
+  double* dst = sums + (long)(blockIdx.x % DY_BN_BWD_REPLICAS) * 2 * C;
+  for (int i = tid; i < nch; i += NT) {
+    const int c = c0 + i;
     if (c < C) {
-      atomic_add_f64(sums + c, (double)sred[i]);
-      if (has_bn) atomic_add_f64(sums + C + c, (double)sred[cgb * VE + i]);
+      atomic_add_f64(dst + c, (double)sred[i]);
+      if (has_bn) atomic_add_f64(dst + C + c, (double)sred[nch + i]);
     }
   }
 }
 
+// backward pass 2: dz = k1*g - (K2*zhat + K3) with k1 = gamma*invstd, K2 = k1*sum(g*zhat)/M, K3 = k1*sum(g)/M
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
                                                                long z_ld, const float* __restrict__ scale,
@@ -183,64 +228,82 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
                                                                T* __restrict__ dz, long dz_ld, float* dgamma, float* dbeta,
                                                                long pixels, long count, int C, int cgb, int rows) {
   constexpr int VE = DT<T>::VE;
-  if (blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < cgb * VE; i += NT) {
-      int c = blockIdx.y * cgb * VE + i;
-      if (c < C) {
-        if (dbeta) dbeta[c] = (float)sums[c];
-        if (dgamma && has_bn) dgamma[c] = (float)sums[C + c];
+  extern __shared__ float lds[];               // [7][nch]: sc, sh, mu, is, k1, K2, K3
+  const int nch = cgb * VE, c0 = blockIdx.y * nch;
+  const float invM = 1.f / (float)count;
+  for (int i = threadIdx.x; i < nch; i += NT) {
+    const int c = c0 + i;
+    const bool ok = c < C;
+    double t1 = 0.0, t2 = 0.0;
+    if (ok) {
+#pragma unroll
+      for (int r = 0; r < DY_BN_BWD_REPLICAS; ++r) {
+        t1 += sums[(long)r * 2 * C + c];
+        if (has_bn) t2 += sums[(long)r * 2 * C + C + c];
+      }
+      if (blockIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)t1;
+        if (dgamma && has_bn) dgamma[c] = (float)t2;
       }
     }
+    const float isv = (has_bn && ok) ? invstd[c] : 0.f;
+    const float k1 = has_bn ? ((gamma && ok) ? gamma[c] : 1.f) * isv : 1.f;
+    lds[i] = (scale && ok) ? scale[c] : 1.f;
+    lds[nch + i] = (shift && ok) ? shift[c] : 0.f;
+    lds[2 * nch + i] = (has_bn && ok) ? mean[c] : 0.f;
+    lds[3 * nch + i] = isv;
+    lds[4 * nch + i] = k1;
+    lds[5 * nch + i] = has_bn ? k1 * ((float)t2 * invM) : 0.f;
+    lds[6 * nch + i] = has_bn ? k1 * ((float)t1 * invM) : 0.f;
   }
+  __syncthreads();
   const Map m = make_map<VE>(C, cgb, rows);
   if (!m.active) return;
-  const float invM = 1.f / (float)count;
-  float sc[VE], sh[VE], mu[VE], is[VE], k1[VE], ka[VE], kb[VE];
+  float sc[VE], sh[VE], mu[VE], is[VE], k1[VE], k2[VE], k3[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    sc[e] = scale ? scale[m.c + e] : 1.f;
-    sh[e] = shift ? shift[m.c + e] : 0.f;
-    mu[e] = has_bn ? mean[m.c + e] : 0.f;
-    is[e] = has_bn ? invstd[m.c + e] : 0.f;
-    k1[e] = has_bn ? (gamma ? gamma[m.c + e] : 1.f) * is[e] : 1.f;
-    ka[e] = has_bn ? (float)sums[m.c + e] * invM : 0.f;
-    kb[e] = has_bn ? (float)sums[C + m.c + e] * invM : 0.f;
+    sc[e] = lds[m.cl + e];
+    sh[e] = lds[nch + m.cl + e];
+    mu[e] = lds[2 * nch + m.cl + e];
+    is[e] = lds[3 * nch + m.cl + e];
+    k1[e] = lds[4 * nch + m.cl + e];
+    k2[e] = lds[5 * nch + m.cl + e];
+    k3[e] = lds[6 * nch + m.cl + e];
   }
-  for (long pa = m.first; pa < pixels; pa += 2 * m.step) {
-    const long pb = pa + m.step;
-    const bool hb = pb < pixels;
-    float ga[VE], za[VE], gb[VE], zb[VE];
-    ldvec<T>(dy + pa * dy_ld + m.c, ga);
-    ldvec<T>(z + pa * z_ld + m.c, za);
-    if (hb) {
-      ldvec<T>(dy + pb * dy_ld + m.c, gb);
-      ldvec<T>(z + pb * z_ld + m.c, zb);
-    }
+  for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
+    float g[UN][VE], zz[UN][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float ge = ga[e] * dy_dact(act, za[e] * sc[e] + sh[e]);
-      ga[e] = k1[e] * (ge - ka[e] - (za[e] - mu[e]) * is[e] * kb[e]);
-    }
-    stvec<T>(dz + pa * dz_ld + m.c, ga);
-    if (hb) {
-#pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        float ge = gb[e] * dy_dact(act, zb[e] * sc[e] + sh[e]);
-        gb[e] = k1[e] * (ge - ka[e] - (zb[e] - mu[e]) * is[e] * kb[e]);
+    for (int k = 0; k < UN; ++k) {
+      const long p = p0 + k * m.step;
+      if (p < pixels) {
+        ldvec<T>(dy + p * dy_ld + m.c, g[k]);
+        ldvec<T>(z + p * z_ld + m.c, zz[k]);
       }
-      stvec<T>(dz + pb * dz_ld + m.c, gb);
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const long p = p0 + k * m.step;
+      if (p < pixels) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float ge = g[k][e] * dact_f(act, zz[k][e] * sc[e] + sh[e]);
+          g[k][e] = k1[e] * ge - (k2[e] * ((zz[k][e] - mu[e]) * is[e]) + k3[e]);
+        }
+        stvec<T>(dz + p * dz_ld + m.c, g[k]);
+      }
     }
   }
 }
 
 struct Geo { int cgb, rows; dim3 grid; };
 
-Geo geometry(long pixels, int C, int ve, int max_x) {
+// ppt: pixels per thread the grid is sized for (more -> fewer blocks -> fewer atomics / less per-block prologue)
+Geo geometry(long pixels, int C, int ve, int ppt, int max_x) {
   Geo g;
   const int CG = C / ve;
   g.cgb = CG < NT ? CG : NT;
   g.rows = NT / g.cgb;
-  long want = (pixels + 2L * g.rows - 1) / (2L * g.rows);       // two pixels per thread per iteration
+  long want = (pixels + (long)ppt * g.rows - 1) / ((long)ppt * g.rows);
   int gx = (int)(want > max_x ? max_x : (want < 1 ? 1 : want));
   g.grid = dim3(gx, dy_cdiv(CG, g.cgb));
   return g;
@@ -260,7 +323,7 @@ extern "C" int dy_bn_finalize(const double* stats, int64_t count, const float* g
                               float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                               float* invstd, int C, void* stream) {
   DY_CHECK(stats && scale && shift && mean && invstd && C > 0 && count > 0, "dy_bn_finalize: bad args");
-  bn_finalize_kernel<<<dy_cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(stats, (double)count, gamma, beta, running_mean,
+  bn_finalize_kernel<<<dy_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, (double)count, gamma, beta, running_mean,
                                                                        running_var, momentum, eps, scale, shift, mean,
                                                                        invstd, C);
   DY_LAUNCH_CHECK();
@@ -282,13 +345,15 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   if (int e = check_view("dy_bn_act_fwd(y)", y, y_ld, C, dtype)) return e;
   if (residual) if (int e = check_view("dy_bn_act_fwd(res)", residual, res_ld, C, dtype)) return e;
   if (pixels <= 0) return 0;
-  const Geo g = geometry(pixels, C, dtype == DY_F32 ? 4 : 8, 4096);
+  const int ve = dtype == DY_F32 ? 4 : 8;
+  const Geo g = geometry(pixels, C, ve, 4, 8192);
+  const size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_fwd_kernel<float><<<g.grid, NT, 0, st>>>((const float*)z, z_ld, scale, shift, act, (const float*)residual, res_ld,
+    bn_act_fwd_kernel<float><<<g.grid, NT, shm, st>>>((const float*)z, z_ld, scale, shift, act, (const float*)residual, res_ld,
                                                     (float*)y, y_ld, pixels, C, g.cgb, g.rows);
   else
-    bn_act_fwd_kernel<bf16_t><<<g.grid, NT, 0, st>>>((const bf16_t*)z, z_ld, scale, shift, act, (const bf16_t*)residual, res_ld,
+    bn_act_fwd_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)z, z_ld, scale, shift, act, (const bf16_t*)residual, res_ld,
                                                      (bf16_t*)y, y_ld, pixels, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();
   return 0;
@@ -302,8 +367,8 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_reduce: null stats");
   if (pixels <= 0) return 0;
   const int ve = dtype == DY_F32 ? 4 : 8;
-  const Geo g = geometry(pixels, C, ve, 1024);
-  size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
+  const Geo g = geometry(pixels, C, ve, 8, 1024);
+  size_t shm = 6 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
     bn_act_bwd_reduce_kernel<float><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
@@ -324,14 +389,16 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   if (int e = check_view("dy_bn_act_bwd_apply(dz)", dz, dz_ld, C, dtype)) return e;
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_apply: null stats");
   // pixels == 0: only the parameter gradients (dgamma / dbeta) are written
-  const Geo g = geometry(pixels > 0 ? pixels : 1, C, dtype == DY_F32 ? 4 : 8, 4096);
+  const int ve = dtype == DY_F32 ? 4 : 8;
+  const Geo g = geometry(pixels > 0 ? pixels : 1, C, ve, 4, 8192);
+  const size_t shm = 7 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_bwd_apply_kernel<float><<<g.grid, NT, 0, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean, invstd,
+    bn_act_bwd_apply_kernel<float><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean, invstd,
                                                           gamma, act, has_bn, sums, (float*)dz, dz_ld, dgamma, dbeta, pixels,
                                                           pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
   else
-    bn_act_bwd_apply_kernel<bf16_t><<<g.grid, NT, 0, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift, mean,
+    bn_act_bwd_apply_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift, mean,
                                                            invstd, gamma, act, has_bn, sums, (bf16_t*)dz, dz_ld, dgamma, dbeta,
                                                            pixels, pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();

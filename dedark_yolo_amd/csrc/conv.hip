@@ -46,7 +46,20 @@ struct ConvP {
   int tiles_n;
   int nblk;
   int ablate;   // DY_ABLATE env (diagnostics only): 1 skip global loads, 2 skip MFMA, 4 skip stores, 8 skip LDS restage
+  long dst_row, dst_img;          // destination row / image strides in elements (dst_row == 0: dense, offset = m * dst_ld)
+  int kh0, khs, kw0, kws, KWf;    // window tap (th, tw) -> weight tap (kh0 + khs*th, kw0 + kws*tw) of a KWf-wide pack
+  long w_row;                     // elements per output-channel row of the weight pack (KHf*KWf*Cs)
 };
+
+template <typename PP>
+__device__ inline long dst_offset(const PP& p, long m) {
+  if (p.dst_row == 0) return m * p.dst_ld;
+  const long HWd = (long)p.Hd * p.Wd;
+  const long img = m / HWd;
+  const int rem = (int)(m - img * HWd);
+  const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+  return img * p.dst_img + (long)oh * p.dst_row + (long)ow * p.dst_ld;
+}
 
 __device__ inline int xcd_remap(int bid, int nblk) {
   // bijective: blocks b, b+8, ... share an XCD; give each XCD a contiguous chunk of tile ids
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
   for (int j = 0; j < BR; ++j) {
     int n = n0 + r0 + 32 * j;
     b_ok[j] = n < p.Cd;
-    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.Ktot + kcur) * (long)sizeof(T);
+    b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * p.w_row * (long)sizeof(T);
   }
 
   u32x4 ra[AR], rb[BR];
@@ -178,10 +191,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
       if (ok) v = *reinterpret_cast<const u32x4*>(a_base[i] + (((long)sh * p.Ws + sw) * p.src_ld + ci) * (long)sizeof(T));
       ra[i] = v;
     }
+    const long wk =((long)((p.kh0 + p.khs * kh) * p.KWf + p.kw0 + p.kws * kw) * p.Cs + ci) * (long)sizeof(T);
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (kvalid && b_ok[j]) v = *reinterpret_cast<const u32x4*>(b_ptr[j]);
+      if (kvalid && b_ok[j]) v = *reinterpret_cast<const u32x4*>(b_ptr[j] + wk);
       rb[j] = v;
     }
   };
@@ -192,8 +206,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
       ci -= p.Cs;
       if (++kw == p.KW) { kw = 0; ++kh; }
     }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) b_ptr[j] += BK * sizeof(T);
   };
   auto store_step = [&]() {
 #pragma unroll
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
           csum[j] += a;
           csq[j] += a * a;
           float v = dy_act(p.act, a * sc + sf);
-          T* o = dst + m * p.dst_ld + n;
+          T* o = dst + dst_offset(p, m) + n;
           if (p.accumulate) v += DT<T>::ld(o);
           if (!(p.ablate & 4)) DT<T>::st(o, v);
         }
@@ -547,6 +559,41 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// all weights of a model in one launch: block b belongs to the item with first_block <= b < next.first_block
+constexpr int PACK_PER_BLOCK = 1024;
+__global__ __launch_bounds__(256) void pack_multi_kernel(const dy_pack_item* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {                      // last item with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const dy_pack_item it = items[lo];
+  const long total = (long)it.Cout_pad * it.KH * it.KW * it.Cin_pad;
+  const long base = (b - it.first_block) * PACK_PER_BLOCK;
+#pragma unroll
+  for (int k = 0; k < PACK_PER_BLOCK / 256; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i >= total) break;
+    int co, kh, kw, ci;
+    long r = i;
+    if (!it.transposed) {
+      ci = (int)(r % it.Cin_pad); r /= it.Cin_pad;
+      kw = (int)(r % it.KW); r /= it.KW;
+      kh = (int)(r % it.KH); r /= it.KH;
+      co = (int)r;
+    } else {
+      co = (int)(r % it.Cout_pad); r /= it.Cout_pad;
+      kw = (int)(r % it.KW); r /= it.KW;
+      kh = (int)(r % it.KH); r /= it.KH;
+      ci = (int)r;
+    }
+    const float v = (ci < it.Cin && co < it.Cout) ? it.w[(((long)co * it.Cin + ci) * it.KH + kh) * it.KW + kw] : 0.f;
+    if (it.dtype == DY_F32) ((float*)it.packed)[i] = v;
+    else ((bf16_t*)it.packed)[i] = f32_to_bf16(v);
+  }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cout, int Cin, int Cin_pad,
                                     int KH, int KW) {
   long total = (long)Cout * Cin * KH * KW;
@@ -571,6 +618,15 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st) {
   p.Ktot = d->KH * d->KW * d->Cs;
   static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
   p.ablate = ablate;
+  p.dst_row = d->dst_row_stride;
+  p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
+  if (d->KHf > 0) {
+    p.kh0 = d->kh0; p.khs = d->kh_step; p.kw0 = d->kw0; p.kws = d->kw_step; p.KWf = d->KWf;
+    p.w_row = (long)d->KHf * d->KWf * d->Cs;
+  } else {
+    p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = d->KW;
+    p.w_row = p.Ktot;
+  }
   constexpr int BM = 128;
   const int tiles_m = dy_cdiv(p.M, BM);
   if (d->Cd <= 32) {
@@ -624,6 +680,52 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   const int wo = (d->Wd + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   DY_CHECK(ho == d->Hs && wo == d->Ws, "dy_conv2d_dgrad: dz %dx%d does not match conv output %dx%d", d->Hs, d->Ws, ho, wo);
   DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
+  DY_CHECK(d->KHf == 0 && d->dst_row_stride == 0, "dy_conv2d_dgrad: tap subsets / strided destinations are forward-only");
+  static const bool no_parity = getenv("DY_NO_PARITY_DGRAD") != nullptr;
+  if (d->stride == 2 && d->dil == 1 && !no_parity) {
+    // Stride-2 data gradient = 4 independent dense problems, one per parity class (ph, pw) of the output pixel: only the
+    // taps kh == (ph + pad) mod 2 reach dx[2*hq + ph], and they read dz[hq + (ph + pad - kh)/2]: a stride-1 correlation over dz
+    // with a 1- or 2-tap window per axis.  The masked formulation visits all KH*KW taps for every pixel (75 % zero work).
+    dy_conv_desc c[4];
+    int nc = 0;
+    bool ok = true;
+    for (int ph = 0; ph < 2 && ok; ++ph)
+      for (int pw = 0; pw < 2 && ok; ++pw) {
+        int geo[2][4];                       // per axis: n taps, first weight tap, pad', extent of the class grid
+        for (int ax = 0; ax < 2; ++ax) {
+          const int par = ax == 0 ? ph : pw, K = ax == 0 ? d->KH : d->KW, ext = ax == 0 ? d->Hd : d->Wd;
+          const int first = (par + d->pad) & 1;                    // smallest valid tap
+          const int n = first < K ? (K - 1 - first) / 2 + 1 : 0;
+          const int last = first + 2 * (n - 1);                    // largest valid tap = smallest source offset
+          const int omin = (par + d->pad - last) / 2;              // exact: same parity
+          geo[ax][0] = n; geo[ax][1] = last; geo[ax][2] = -omin; geo[ax][3] = (ext - par + 1) / 2;
+        }
+        if (geo[0][3] <= 0 || geo[1][3] <= 0) continue;            // no pixel of this parity
+        if (geo[0][0] == 0 || geo[1][0] == 0 || geo[0][2] != geo[1][2] || geo[0][2] < 0) { ok = false; break; }
+        dy_conv_desc& q = c[nc++];
+        q = *d;
+        const long es = d->dtype == DY_F32 ? 4 : 2;
+        q.dst = (char*)d->dst + ((long)ph * d->Wd + pw) * d->dst_ld * es;
+        q.dst_ld = 2 * d->dst_ld;
+        q.dst_row_stride = 2L * d->Wd * d->dst_ld;
+        q.dst_img_stride = (long)d->Hd * d->Wd * d->dst_ld;
+        q.Hd = geo[0][3]; q.Wd = geo[1][3];
+        q.KHf = d->KH; q.KWf = d->KW;
+        q.KH = geo[0][0]; q.KW = geo[1][0];
+        q.kh0 = geo[0][1]; q.kh_step = -2; q.kw0 = geo[1][1]; q.kw_step = -2;
+        q.stride = 1; q.pad = geo[0][2];
+      }
+    if (ok) {
+      for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
+        const dy_conv_desc* q = &c[i];
+        int e;
+        if (dy_conv_v2_eligible(q)) e = dy_conv_v2_launch(q, 0, stream);
+        else e = q->dtype == DY_F32 ? launch_conv<float, 0>(q, (hipStream_t)stream) : launch_conv<bf16_t, 0>(q, (hipStream_t)stream);
+        if (e) return e;
+      }
+      return 0;
+    }
+  }
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;
@@ -707,6 +809,17 @@ extern "C" int dy_pack_weight(const float* w, void* packed, int Cout, int Cout_p
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32) pack_weight_kernel<float><<<blocks, 256, 0, st>>>(w, (float*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
   else pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, (bf16_t*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t dy_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW) {
+  return ((int64_t)Cout_pad * KH * KW * Cin_pad + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK;
+}
+
+extern "C" int dy_pack_weights_multi(const dy_pack_item* items_dev, int n_items, int64_t n_blocks, void* stream) {
+  DY_CHECK(items_dev && n_items > 0 && n_blocks > 0 && n_blocks < (1LL << 31), "dy_pack_weights_multi: bad args");
+  pack_multi_kernel<<<(unsigned)n_blocks, 256, 0, (hipStream_t)stream>>>(items_dev, n_items);
   DY_LAUNCH_CHECK();
   return 0;
 }

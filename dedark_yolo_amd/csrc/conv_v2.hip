@@ -51,7 +51,19 @@ struct P {
   int Ktot;
   int tiles_n, nblk;
   int ablate;     // DY_ABLATE (diagnostics): 1 no loads after the prologue, 2 no MFMA, 4 no stores, 16 no LDS fragment reads
+  long dst_row, dst_img;          // destination row / image strides in elements (dst_row == 0: dense)
+  int kh0, khs, kw0, kws, KWf;    // window tap -> weight tap mapping (tap subsets of a parity-split data gradient)
+  long w_row;                     // elements per output-channel row of the weight pack
 };
+
+__device__ inline long dst_offset(const P& p, long m) {
+  if (p.dst_row == 0) return m * p.dst_ld;
+  const long HWd = (long)p.Hd * p.Wd;
+  const long img = m / HWd;
+  const int rem = (int)(m - img * HWd);
+  const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+  return img * p.dst_img + (long)oh * p.dst_row + (long)ow * p.dst_ld;
+}
 
 __device__ inline int xcd_remap(int bid, int nblk) {
   int q = nblk >> 3, r = nblk & 7, x = bid & 7;
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   for (int j = 0; j < B_LD; ++j) {
     int n = n0 + 8 * (wave + 8 * j) + lrow;
     b_ok[j] = n < p.Cd;
-    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.Ktot + chunk * 8) * 2;
+    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.w_row + chunk * 8) * 2;
   }
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   int kh = 0, kw = 0, ci = 0;              // tap / channel offset of the NEXT stage to issue
@@ -138,11 +150,11 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
       const char* g = ok ? a_base[j] + (((long)sh * p.Ws + sw) * p.src_ld + ci) * 2 : zero;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
     }
+    const long wk = ((long)((p.kh0 + p.khs * kh) * p.KWf + p.kw0 + p.kws * kw) * p.Cs + ci) * 2;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const char* g = b_ok[j] ? b_ptr[j] : zero;
+      const char* g = b_ok[j] ? b_ptr[j] + wk : zero;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + BM * ROW + (wave + 8 * j) * 1024), 16, 0, 0);
-      b_ptr[j] += BK * 2;
     }
     ci += BK;
     if (ci >= p.Cs) {
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
         const long m = m0 + row;
         if (m >= p.M) break;
         u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * BN + vc * 8);
-        bf16_t* o = dst + m * p.dst_ld + n;
+        bf16_t* o = dst + dst_offset(p, m) + n;
         if (full) {
           if (p.accumulate) {
             float x[8], y[8];
@@ -368,6 +380,15 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   p.Ktot = d->KH * d->KW * d->Cs;
   static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
   p.ablate = ablate;
+  p.dst_row = d->dst_row_stride;
+  p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
+  if (d->KHf > 0) {
+    p.kh0 = d->kh0; p.khs = d->kh_step; p.kw0 = d->kw0; p.kws = d->kw_step; p.KWf = d->KWf;
+    p.w_row = (long)d->KHf * d->KWf * d->Cs;
+  } else {
+    p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = d->KW;
+    p.w_row = p.Ktot;
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool wide = d->Cd > 64;
   if (mode == 0) return wide ? v2::launch<128, 0>(p, st) : v2::launch<64, 0>(p, st);

@@ -402,6 +402,7 @@ bool dy_conv_v3_eligible(const dy_conv_desc* d) {
   static const bool off = getenv("DY_NO_CONV_V3") != nullptr;
   if (off) return false;
   if (!(d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
+  if (d->KHf != 0 || d->dst_row_stride != 0) return false;    // tap subsets / strided destinations: generic kernels only
   if (!(d->Cs % 64 == 0 && d->Cd >= 64 && d->Hs == d->Hd && d->Ws == d->Wd && (d->src_ld * 2) % 16 == 0)) return false;
   if ((long)d->N * d->Hs * d->Ws < 2048) return false;
   v3::P p;

@@ -164,6 +164,7 @@ class DetectionTrainer:
         self.updates = 0
         self.step_count = 0
         self.mse_acc = None
+        self.pack_plan = ops.PackPlan()
 
     # ---------------------------------------------------------------- setup
     def get_model(self, cfg=None, weights=None, nc=None):
@@ -255,6 +256,7 @@ class DetectionTrainer:
         if f.buf_ema is not None and f.buf_flat.numel():
             call("dy_ema_lerp", ptr(f.buf_ema), ptr(f.buf_flat), d, f.buf_flat.numel(), st)
         ops.bump_weights_epoch()
+        self.pack_plan.repack(self.model)
 
     def train_step(self, batch, lr=None, mom=None):
         """preprocess + forward + loss + backward (+ bucketed all-reduce) + optimizer/EMA. Returns (loss, loss_items)."""

@@ -130,21 +130,29 @@ class _Arena:
     def __init__(self):
         self.buf = None
         self.off = 0
+        self.used = 0          # doubles handed out since the last reset
+        self.chunks = 0        # buffers created since the last reset
 
     def alloc(self, n, device):
         n = round_up(n, 2)
+        self.used += n
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
-            cap = max(1 << 18, 4 * n)
+            cap = max(1 << 18, 4 * n)                # overflow chunk; reset() replaces the chunks by one buffer of the right size
             self.buf = torch.zeros(cap, dtype=torch.float64, device=device)
             self.off = 0
+            self.chunks += 1
         out = self.buf[self.off:self.off + n]
         self.off += n
         return out
 
     def reset(self):
-        if self.buf is not None and self.off:
+        if self.chunks > 1 and self.buf is not None:
+            self.buf = torch.zeros(int(self.used * 1.25) + 1024, dtype=torch.float64, device=self.buf.device)
+        elif self.buf is not None and self.off:
             self.buf[:self.off].zero_()
         self.off = 0
+        self.used = 0
+        self.chunks = 1 if self.buf is not None else 0
 
 
 arena = _Arena()
@@ -166,6 +174,49 @@ def _pack(weight, cout_pad, cin_pad, transposed, dtype):
     call("dy_pack_weight", ptr(w32), ptr(out), Co, cout_pad, Ci, cin_pad, KH, KW, 1 if transposed else 0, dt_id(dtype), stream())
     cache[key] = (tag, out)
     return out
+
+
+class PackPlan:
+    """Re-packs every cached packed weight of a model with one launch (dy_pack_weights_multi) right after the optimizer
+    step wrote the f32 masters; the per-conv lazy path of _pack() then only ever hits its cache."""
+
+    def __init__(self):
+        self.sig = None
+        self.table = None
+        self.n_blocks = 0
+        self.entries = []
+
+    def _collect(self, model):
+        ent = []
+        for w in model.parameters():
+            cache = w.__dict__.get("_dy_pack")
+            if not cache or w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4:
+                continue
+            for key, (tag, out) in cache.items():
+                ent.append((w, key, out))
+        return ent
+
+    def repack(self, model):
+        ent = self._collect(model)
+        if not ent:
+            return
+        sig = tuple((w.data_ptr(), out.data_ptr(), key) for w, key, out in ent)
+        if sig != self.sig:
+            items = (_C.PackItem * len(ent))()
+            blk = 0
+            lib = _C.lib()
+            for it, (w, (cout_pad, cin_pad, transposed, dtype), out) in zip(items, ent):
+                Co, Ci, KH, KW = w.shape
+                it.w, it.packed = w.data_ptr(), out.data_ptr()
+                it.Cout, it.Cout_pad, it.Cin, it.Cin_pad, it.KH, it.KW = Co, cout_pad, Ci, cin_pad, KH, KW
+                it.transposed, it.dtype, it.first_block = int(transposed), dt_id(dtype), blk
+                blk += lib.dy_pack_item_blocks(cout_pad, cin_pad, KH, KW)
+            raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+            self.table = raw.to(ent[0][0].device)
+            self.n_blocks, self.sig = blk, sig
+        call("dy_pack_weights_multi", ptr(self.table), len(ent), self.n_blocks, stream())
+        for w, key, out in ent:
+            w.__dict__["_dy_pack"][key] = ((_weights_epoch, w._version), out)
 
 
 def _padded_vec(v, n):
@@ -246,7 +297,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         stats = arena.alloc(2 * cout_pad * _C.STATS_REPLICAS, dev)
         d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
                        False, dtype)
-        _C.set_meta(kind="conv_fwd", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+        _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         aff = torch.empty((4, cout_pad), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
@@ -255,7 +306,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
              cout_pad, stream())
         _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
         y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
-        _C.set_meta(kind="bn_act_fwd", dtype=str(dtype), flops=0.0,
+        _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
                     bytes=float(B * Ho * Wo * cout_pad * x.element_size() * (3 if residual is not None else 2)))
         call("dy_bn_act_fwd", ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), act, ptr(residual),
              ld_of(residual) if residual is not None else 0, ptr(y), ld_of(y), B * Ho * Wo, cout_pad, dt_id(dtype), stream())
@@ -273,7 +324,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         y = out if (out is not None and direct) else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         d = _conv_desc(x, wp, y, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, scale, shift, act, None, False,
                        dtype)
-        _C.set_meta(kind="conv_fwd", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+        _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         if not direct:                  # eval-time residual: y_out = y + residual
@@ -339,8 +390,8 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     st = stream()
     if ctx.has_bn:
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
-        sums = arena.alloc(2 * cout_pad, dev)
-        _C.set_meta(kind="bn_act_bwd_reduce", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
+        sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)
+        _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
         call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
         dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
@@ -349,7 +400,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         if not direct:
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
-        _C.set_meta(kind="bn_act_bwd_apply", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
+        _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
         call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
         if not direct:
@@ -361,7 +412,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         if ctx.act == ACT_NONE and not need_bias:
             dz = dy
         else:
-            sums = arena.alloc(2 * cout_pad, dev)
+            sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)
             call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(y), ld_of(y), None, None, None, None, ctx.act, 0, ptr(sums),
                  pixels, cout_pad, did, st)
             gb_ = _grad_dst(ctx.bias) if (need_bias and cout_pad == Cout) else None
@@ -385,7 +436,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         gd = _grad_dst(ctx.owner)
         gw = gd if gd is not None else torch.empty(ctx.weight.shape, dtype=torch.float32, device=dev)
         scratch = wgrad_scratch(dev)
-        _C.set_meta(kind="conv_wgrad", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+        _C.set_meta(kind="conv_wgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size() + Cout * KH * KW * Cin * 4))
         call("dy_conv2d_wgrad", ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride,
              ctx.pad, ctx.dil, Cout, Cin, ptr(scratch), scratch.numel(), ptr(gw), did, st)
@@ -403,7 +454,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
             raise RuntimeError("conv_backward: dx_out view too narrow")
     d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
                    None, accumulate, dtype)
-    _C.set_meta(kind="conv_dgrad", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+    _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                 bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)
     if dx_out is not None:

@@ -25,6 +25,7 @@ extern "C" {
 #define DY_ACT_SILU 1
 #define DY_ACT_LEAKY 2 /* LeakyReLU(0.1) */
 #define DY_STATS_REPLICAS 64 /* copies of the BN batch-statistics accumulators filled by dy_conv2d_fwd */
+#define DY_BN_BWD_REPLICAS 8 /* copies of the (sum g, sum g*zhat) accumulators of dy_bn_act_bwd_reduce */
 
 const char* dy_last_error(void);
 int dy_version(void);
@@ -49,6 +50,12 @@ typedef struct {
                          output over all pixels, spread over replicas to avoid atomic contention (BN batch stats) */
   int accumulate;     /* 1: dst += result */
   int dtype;          /* DY_F32 | DY_BF16 (src, w, dst) */
+  /* optional extensions, all zero = dense destination / full window (a zero-initialised descriptor keeps the old meaning) */
+  int64_t dst_row_stride; /* elements between destination rows    (0: Wd * dst_ld) */
+  int64_t dst_img_stride; /* elements between destination images  (0: Hd * row stride) */
+  int KHf, KWf;           /* tap subset: `w` is a [Cd][KHf][KWf][Cs] pack and window tap (th, tw) of the KH x KW window uses */
+  int kh0, kh_step;       /* weight tap (kh0 + kh_step*th, kw0 + kw_step*tw).  KHf == 0: no subset.  dy_conv2d_dgrad uses   */
+  int kw0, kw_step;       /* this internally to run a stride-2 data gradient as 4 dense stride-1 problems (one per parity)   */
 } dy_conv_desc;
 
 /* forward: dst[n,ho,wo,:] = epilogue( sum_{kh,kw,c} src[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * w[:,kh,kw,c] ) */
@@ -67,6 +74,16 @@ int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin_
  * (transposed=1) in `dtype`; padded input/output channels are written as zero. */
 int dy_pack_weight(const float* w_oihw, void* packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int KH, int KW,
                    int transposed, int dtype, void* stream);
+/* The same for every weight of a model in ONE launch (after each optimizer step): `items_dev` is a DEVICE array sorted by
+ * first_block; item i owns thread blocks [first_block, first_block + dy_pack_item_blocks(...)); n_blocks = their sum. */
+typedef struct {
+  const float* w;   /* f32 OIHW master weight */
+  void* packed;     /* destination, `dtype` elements */
+  int Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed, dtype;
+  int64_t first_block;
+} dy_pack_item;
+int64_t dy_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW);
+int dy_pack_weights_multi(const dy_pack_item* items_dev, int n_items, int64_t n_blocks, void* stream);
 /* packed f32 grad [Cout][KH][KW][Cin_pad] -> OIHW f32 (overwrite) */
 int dy_unpack_wgrad(const float* dw_packed, float* g_oihw, int Cout, int Cin, int Cin_pad, int KH, int KW, void* stream);
 
@@ -85,7 +102,9 @@ int dy_bn_fold_eval(const float* gamma, const float* beta, const float* running_
 int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, const float* shift, int act, const void* residual,
                   int64_t res_ld, void* y, int64_t y_ld, int64_t pixels, int C, int dtype, void* stream);
 /* backward pass 1: sums[0:C] = sum g, sums[C:2C] = sum g*zhat with g = dy*act'(u), u = z*scale+shift,
- * zhat = (z-mean)*invstd (has_bn) ; without BN only sum g (bias gradient). `sums` (double) must be zeroed. */
+ * zhat = (z-mean)*invstd (has_bn) ; without BN only sum g (bias gradient).
+ * `sums` is [DY_BN_BWD_REPLICAS][2C] doubles, zeroed by the caller; thread blocks spread their atomics over the replicas
+ * and dy_bn_act_bwd_apply adds them up. */
 int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, const float* scale,
                          const float* shift, const float* mean, const float* invstd, int act, int has_bn, double* sums,
                          int64_t pixels, int C, int dtype, void* stream);

@@ -119,9 +119,13 @@ if __name__ == "__main__":
         conv_case(dt, 1, 32, 8, 10, 9, 3, 1, 2, 2)
         conv_case(dt, 2, 256, 256, 8, 8, 3, 1, 1)
         conv_case(dt, 2, 8, 16, 33, 31, 5, 1, 2)
+        conv_case(dt, 2, 16, 32, 13, 21, 3, 2, 1)       # stride-2 dgrad = 4 parity classes, odd sizes
+        conv_case(dt, 2, 8, 16, 12, 14, 1, 2, 0)        # k1 s2: empty parity classes -> masked fallback
+        conv_case(dt, 1, 8, 16, 17, 16, 5, 2, 2)        # k5 s2: unequal class pads -> masked fallback
         if dt == torch.bfloat16:      # shapes routed to the pipelined kernel (conv_v2.hip): M >= 2048, Cin % 64 == 0
             conv_case(dt, 2, 64, 128, 40, 40, 3, 1, 1)
             conv_case(dt, 3, 128, 64, 32, 32, 3, 2, 1)
+            conv_case(dt, 2, 64, 128, 65, 63, 3, 2, 1)  # parity-split dgrad on the pipelined kernel (strided destination)
             conv_case(dt, 2, 256, 192, 48, 48, 1, 1, 0)
             conv_case(dt, 1, 64, 64, 50, 47, 3, 1, 1)
             conv_case(dt, 2, 192, 320, 24, 24, 3, 1, 1)

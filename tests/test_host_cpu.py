@@ -64,7 +64,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "dedark_yolo.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(dy_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(dy_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
         args = m.group(2).strip()
         decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     assert len(decls) > 30
