@@ -21,6 +21,9 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
 // band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
 int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
+// direct stem kernels (conv_small.hip)
+bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
+int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream);
 
 namespace {
 
@@ -247,23 +250,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
   T* dst = reinterpret_cast<T*>(p.dst);
+  int nn[TN];
+  bool nok[TN];
+  float sc[TN], sf[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / WN) + j * 32 + cl;
-    const bool nok = n < p.Cd;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sf = (nok && p.shift) ? p.shift[n] : 0.f;
+    nn[j] = n0 + wn * (BN / WN) + j * 32 + cl;
+    nok[j] = nn[j] < p.Cd;
+    sc[j] = (nok[j] && p.scale) ? p.scale[nn[j]] : 1.f;
+    sf[j] = (nok[j] && p.shift) ? p.shift[nn[j]] : 0.f;
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (nok && m < p.M) {
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (m >= p.M) continue;
+      T* orow = dst + dst_offset(p, m);          // one pixel decode per row (strided destinations of the parity-split dgrad)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (nok[j]) {
           float a = acc[i][j][r];
           csum[j] += a;
           csq[j] += a * a;
-          float v = dy_act(p.act, a * sc + sf);
-          T* o = dst + dst_offset(p, m) + n;
+          float v = dy_act(p.act, a * sc[j] + sf[j]);
+          T* o = orow + nn[j];
           if (p.accumulate) v += DT<T>::ld(o);
           if (!(p.ablate & 4)) DT<T>::st(o, v);
         }
@@ -681,6 +692,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   DY_CHECK(ho == d->Hs && wo == d->Ws, "dy_conv2d_dgrad: dz %dx%d does not match conv output %dx%d", d->Hs, d->Ws, ho, wo);
   DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
   DY_CHECK(d->KHf == 0 && d->dst_row_stride == 0, "dy_conv2d_dgrad: tap subsets / strided destinations are forward-only");
+  if (dy_conv_small_dgrad_eligible(d)) return dy_conv_small_dgrad_launch(d, stream);
   static const bool no_parity = getenv("DY_NO_PARITY_DGRAD") != nullptr;
   if (d->stride == 2 && d->dil == 1 && !no_parity) {
     // Stride-2 data gradient = 4 independent dense problems, one per parity class (ph, pw) of the output pixel: only the

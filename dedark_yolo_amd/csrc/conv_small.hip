@@ -1,0 +1,122 @@
+// Direct (non-MFMA) kernels for the network stem, where the implicit-GEMM tiles are mostly padding.
+//
+// dgrad of a 3x3 / stride 2 / pad 1 convolution into a <= 8-channel image (Conv(3, c, 3, 2) of yolov8*.yaml layer 1, the first
+// ConvBlock of the parameter extractor, reference ultralytics/nn/modules/conv.py:38-55 / common.py:9-23):
+//   dx[n, h, w, ci] = sum_{kh, kw, co} dz[n, (h+1-kh)/2, (w+1-kw)/2, co] * w[co, ci, kh, kw]      (terms with odd h+1-kh dropped)
+// One thread owns a 2x2 quad of output pixels: the quad touches exactly the 2x2 block of dz pixels (qh..qh+1, qw..qw+1) and
+// every one of the 9 taps once.  dz pixels stay packed (bf16 pairs) in VGPRs, the weights are wave-uniform and come through
+// the scalar cache straight into the SGPR operand of v_dot2c_f32_bf16 (2 MACs per lane per instruction, f32 accumulate).
+// The kernel is HBM-bound: it reads dz once and writes dx once.  The MFMA formulation (128x32 tiles for 8 output channels,
+// K = 16..64 per parity class) took 1.08 ms on the 32x640x640 stem; this kernel is bounded by ~315 MB of traffic.
+#include "dy_common.h"
+#include "../../include/dedark_yolo.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ inline float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
+template <int CS, int NCI>
+__global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __restrict__ dz, long dz_ld,
+                                                                const uint32_t* __restrict__ wt, bf16_t* __restrict__ dx,
+                                                                long dx_ld, int N, int Hd, int Wd, int Hs, int Ws,
+                                                                int accumulate) {
+  constexpr int NP = CS / 2;                         // packed pairs per pixel
+  const int QH = (Hd + 1) >> 1, QW = (Wd + 1) >> 1;
+  const long q = blockIdx.x * 256L + threadIdx.x;
+  if (q >= (long)N * QH * QW) return;
+  const int qw = (int)(q % QW);
+  const long t = q / QW;
+  const int qh = (int)(t % QH), n = (int)(t / QH);
+
+  uint32_t P[2][2][NP];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = qh + a, c = qw + b;
+      const bool ok = r < Hs && c < Ws;
+      const u32x4* src = reinterpret_cast<const u32x4*>(dz + (((long)n * Hs + (ok ? r : 0)) * Ws + (ok ? c : 0)) * dz_ld);
+#pragma unroll
+      for (int v = 0; v < NP / 4; ++v) {
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (ok) x = src[v];
+        P[a][b][4 * v + 0] = x[0]; P[a][b][4 * v + 1] = x[1]; P[a][b][4 * v + 2] = x[2]; P[a][b][4 * v + 3] = x[3];
+      }
+    }
+
+  float acc[2][2][NCI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ci = 0; ci < NCI; ++ci) acc[i][j][ci] = 0.f;
+
+  // output row parity dh: even rows see tap kh = 1 (source row qh), odd rows taps kh = 0 (source qh+1) and kh = 2 (source qh)
+#pragma unroll
+  for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int dh = kh == 1 ? 0 : 1, a = kh == 0 ? 1 : 0;
+        const int dw = kw == 1 ? 0 : 1, b = kw == 0 ? 1 : 0;
+        const uint32_t* w = wt + ((ci * 3 + kh) * 3 + kw) * NP;       // wave-uniform -> s_load
+        float s = acc[dh][dw][ci];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s = dot2(P[a][b][p], w[p], s);
+        acc[dh][dw][ci] = s;
+      }
+
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      const int h = 2 * qh + dh, w = 2 * qw + dw;
+      if (h < Hd && w < Wd) {
+        bf16_t* o = dx + (((long)n * Hd + h) * Wd + w) * dx_ld;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (accumulate) ldvec<bf16_t>(o, v);
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) v[ci] += acc[dh][dw][ci];
+        stvec<bf16_t>(o, v);
+      }
+    }
+}
+
+template <int CS>
+int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
+  const long quads = (long)d->N * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
+  const unsigned grid = (unsigned)((quads + 255) / 256);
+  const int nci = d->dst_valid_channels > 0 && d->dst_valid_channels <= 4 ? 4 : 8;
+#define GO(NCI)                                                                                                              \
+  dgrad3x3s2_small_kernel<CS, NCI><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const uint32_t*)d->w, (bf16_t*)d->dst, \
+                                                         d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate)
+  if (nci == 4) GO(4); else GO(8);
+#undef GO
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d) {
+  static const bool off = getenv("DY_NO_CONV_SMALL") != nullptr;
+  if (off) return false;
+  return d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1 && d->Cd == 8 &&
+         (d->Cs == 16 || d->Cs == 32 || d->Cs == 64) && d->KHf == 0 && d->dst_row_stride == 0 && (d->src_ld * 2) % 16 == 0 &&
+         (d->dst_ld * 2) % 16 == 0;
+}
+
+int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (d->Cs == 16) return launch_small_dgrad<16>(d, st);
+  if (d->Cs == 32) return launch_small_dgrad<32>(d, st);
+  return launch_small_dgrad<64>(d, st);
+}

@@ -2,18 +2,14 @@
 // filters of ultralytics/nn/modules/filtersB.py (DeDark :190-216, ImprovedWhiteBalance :246-259, Gamma :227-233,
 // Contrast :296-303 with rgb2lum util_filters.py:270-273, Usm :151-175).  All fp32 math, HBM-bound.
 //
-//   x[B,3,H,W] --pointwise chain--> s4 --separable 25-tap gaussian (reflect halo 12) + unsharp combine--> out
+//   x[B,3,H,W] --pointwise chain--> s4 --separable 25-tap gaussian (reflect halo 12) + unsharp combine (usm.hip)--> out
 // The reference launches ~12 full-image passes (clone x2, pad, 3 dense 625-tap conv2d, cat, ...); here: one pointwise
-// kernel (1R+1W), one USM kernel (1R + 1W f32 + optional NHWC8 copy for the stem conv).  The blur is done separably in
-// LDS (50 taps instead of 625).  Must-reproduce quirk: `lum` of the contrast filter is a per-(b,c,row) scalar taken from
+// kernel (1R+1W), one USM kernel (1R + 1W f32 + optional NHWC8 copy for the stem conv).  Must-reproduce quirk: `lum` of the contrast filter is a per-(b,c,row) scalar taken from
 // pixel columns 0,1,2 of the gamma-filtered image.
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
 namespace {
-
-constexpr int R = 12;           // gaussian radius
-__constant__ float c_taps[R + 1];   // k[|d|], sigma 5, normalised (filtersB.py:152-161)
 
 struct FParams { float omega, s[3], gamma, alpha, lam; };
 
@@ -22,21 +18,6 @@ __device__ inline FParams load_params(const float* params, int b) {
   const float* q = params + b * 8;
   p.omega = q[0]; p.s[0] = q[1]; p.s[1] = q[2]; p.s[2] = q[3]; p.gamma = q[4]; p.alpha = q[5]; p.lam = q[6];
   return p;
-}
-
-// chain up to the gamma filter for one pixel
-__device__ inline float chain_s3(float x, float A, float I, const FParams& p, int c, float* s1_out, float* s2_out) {
-  float tx = fmaxf(1.f - p.omega * I, 0.01f);
-  float s1 = (x - A) / tx + A;
-  float s2 = s1 * p.s[c];
-  if (s1_out) *s1_out = s1;
-  if (s2_out) *s2_out = s2;
-  return powf(fmaxf(s2, 1e-4f), p.gamma);
-}
-
-__device__ inline float contrast_gain(float lum, float alpha) {
-  float cl = -cosf(3.14159265358979323846f * lum) * 0.5f + 0.5f;
-  return (1.f - alpha) + alpha * cl / (lum + 1e-6f);
 }
 
 // ---- image relayout (+ optional bilinear resize, align_corners=False) ------------------------------------------------
@@ -146,288 +127,144 @@ __global__ void filter_params_bwd_kernel(const float* __restrict__ feat, int fea
   o[14] = g[6] * 2.5f * (1.f - t14 * t14);
 }
 
-// ---- pointwise chain: one block per (b, c, row) ---------------------------------------------------------------------
+// ---- pointwise chain: one WAVE per (b, c, row), four rows per block ---------------------------------------------------
+// pow(x, g) = exp2(g * log2(x)) on the hardware transcendentals (v_log_f32 / v_exp_f32, ~1e-6 relative for x >= 1e-4,
+// g <= 3): the libm powf/logf sequence made both kernels ALU-bound (1.1 ms backward for 471 MB of traffic).  Reductions are
+// wave shuffles; the block only meets in LDS to merge its four rows' parameter gradients into one set of atomics.
+constexpr int PW_ROWS = 4;
+constexpr float LN2 = 0.69314718055994530942f;
+
+struct Px { float s1, s2, base, L, s3, rtx, txr; };
+
+__device__ inline Px chain_px(float x, float A, float I, const FParams& p, int c) {
+  Px r;
+  r.txr = 1.f - p.omega * I;
+  r.rtx = __builtin_amdgcn_rcpf(fmaxf(r.txr, 0.01f));
+  r.s1 = (x - A) * r.rtx + A;
+  r.s2 = r.s1 * p.s[c];
+  r.base = fmaxf(r.s2, 1e-4f);
+  r.L = __builtin_amdgcn_logf(r.base);           // v_log_f32 = log2
+  r.s3 = __builtin_amdgcn_exp2f(p.gamma * r.L);  // v_exp_f32 = 2^x
+  return r;
+}
+
+__device__ inline float row_lum(const float* xr, const float* ir, float Ac, const FParams& p, int c, int lane, int W, float* lraw_out) {
+  float v = 0.f;
+  if (lane < 3 && lane < W) v = chain_px(xr[lane], Ac, ir ? ir[lane] : 0.5f, p, c).s3;
+  const float lraw = 0.27f * __shfl(v, 0, 64) + 0.67f * __shfl(v, 1, 64) + 0.06f * __shfl(v, 2, 64);
+  *lraw_out = lraw;
+  return fminf(fmaxf(lraw, 0.f), 1.f);
+}
+
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params,
                                                              const float* __restrict__ A, const float* __restrict__ IcA,
                                                              float* __restrict__ s4, int B, int H, int W) {
-  __shared__ float s_l[3];
-  const int row = blockIdx.x;                // (b*3 + c)*H + h
-  const int h = row % H, bc = row / H, c = bc % 3, b = bc / 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * PW_ROWS + wave;                // (b*3 + c)*H + h
+  if (row >= (long)B * 3 * H) return;
+  const int h = (int)(row % H), bc = (int)(row / H), c = bc % 3, b = bc / 3;
   const FParams p = load_params(params, b);
   const float Ac = A ? A[b * 3 + c] : 0.8f;
-  const float* xr = x + (long)row * W;
+  const float* xr = x + row * W;
   const float* ir = IcA ? IcA + ((long)b * H + h) * W : nullptr;
-  if (threadIdx.x < 3) s_l[threadIdx.x] = chain_s3(xr[threadIdx.x], Ac, ir ? ir[threadIdx.x] : 0.5f, p, c, nullptr, nullptr);
-  __syncthreads();
-  const float lum = fminf(fmaxf(0.27f * s_l[0] + 0.67f * s_l[1] + 0.06f * s_l[2], 0.f), 1.f);
-  const float K = contrast_gain(lum, p.alpha);
-  float* o = s4 + (long)row * W;
-  for (int w = threadIdx.x; w < W; w += blockDim.x) {
-    float s3 = chain_s3(xr[w], Ac, ir ? ir[w] : 0.5f, p, c, nullptr, nullptr);
-    // lerp(img, img/(lum+1e-6)*cl, alpha) written as the reference does (util_filters.py:316-317)
-    float cl = -cosf(3.14159265358979323846f * lum) * 0.5f + 0.5f;
-    float ci = s3 / (lum + 1e-6f) * cl;
-    o[w] = (1.f - p.alpha) * s3 + p.alpha * ci;
-    (void)K;
-  }
+  float lraw;
+  const float lum = row_lum(xr, ir, Ac, p, c, lane, W, &lraw);
+  // lerp(img, img/(lum+1e-6)*cl, alpha) (util_filters.py:316-317) = img * K with a per-row K
+  const float cl = -cosf(3.14159265358979323846f * lum) * 0.5f + 0.5f;
+  const float K = (1.f - p.alpha) + p.alpha * (cl / (lum + 1e-6f));
+  float* o = s4 + row * W;
+  for (int w = lane; w < W; w += 64) o[w] = chain_px(xr[w], Ac, ir ? ir[w] : 0.5f, p, c).s3 * K;
+}
+
+struct PwAcc { float gamma, wb, om; };
+
+// backward of the chain for one pixel given d(loss)/d(s3); returns d(loss)/dx and accumulates the parameter gradients
+__device__ inline float chain_bwd_px(const Px& q, float x, float A, float I, float d3, const FParams& p, int c, PwAcc& a) {
+  a.gamma += d3 * q.s3 * (q.L * LN2);
+  const float d2 = (q.s2 >= 1e-4f) ? d3 * p.gamma * q.s3 * __builtin_amdgcn_rcpf(q.base) : 0.f;
+  a.wb += d2 * q.s1;
+  const float d1 = d2 * p.s[c];
+  if (q.txr >= 0.01f) a.om += d1 * (x - A) * I * q.rtx * q.rtx;
+  return d1 * q.rtx;
 }
 
 __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ params,
                                                              const float* __restrict__ A, const float* __restrict__ IcA,
                                                              const float* __restrict__ ds4, float* __restrict__ dx,
                                                              float* dparams, int B, int H, int W, int accumulate) {
-  __shared__ float s_l[3];
-  __shared__ float sm[20];
-  const int row = blockIdx.x;
-  const int h = row % H, bc = row / H, c = bc % 3, b = bc / 3;
-  const FParams p = load_params(params, b);
-  const float Ac = A ? A[b * 3 + c] : 0.8f;
-  const float* xr = x + (long)row * W;
-  const float* ir = IcA ? IcA + ((long)b * H + h) * W : nullptr;
-  const float* gr = ds4 + (long)row * W;
-  if (threadIdx.x < 3) s_l[threadIdx.x] = chain_s3(xr[threadIdx.x], Ac, ir ? ir[threadIdx.x] : 0.5f, p, c, nullptr, nullptr);
-  __syncthreads();
-  const float lraw = 0.27f * s_l[0] + 0.67f * s_l[1] + 0.06f * s_l[2];
-  const float lum = fminf(fmaxf(lraw, 0.f), 1.f);
-  const float PI = 3.14159265358979323846f;
-  const float cl = -cosf(PI * lum) * 0.5f + 0.5f;
-  const float q = cl / (lum + 1e-6f);
-  const float K = (1.f - p.alpha) + p.alpha * q;
-  // phase 1: dK_row = sum_w d4*s3 (also d alpha)
-  float part = 0.f;
-  for (int w = threadIdx.x; w < W; w += blockDim.x)
-    part += gr[w] * chain_s3(xr[w], Ac, ir ? ir[w] : 0.5f, p, c, nullptr, nullptr);
-  const float dK = block_sum(part, sm);
-  const float d_alpha = dK * (q - 1.f);
-  // d q / d lum, gated by clamp(lum, 0, 1) (inclusive bounds pass the gradient, as torch.clamp does)
-  float dlum = 0.f;
-  if (lraw >= 0.f && lraw <= 1.f) {
-    float dcl = 0.5f * PI * sinf(PI * lum);
-    dlum = dK * p.alpha * (dcl * (lum + 1e-6f) - cl) / ((lum + 1e-6f) * (lum + 1e-6f));
+  __shared__ float s_part[PW_ROWS][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * PW_ROWS + wave;
+  const bool live = row < (long)B * 3 * H;
+  const bool merged = (H % PW_ROWS) == 0;                            // then the block's rows share (b, c)
+  float t_om = 0.f, t_wb = 0.f, t_gamma = 0.f, t_alpha = 0.f;
+  int b = 0, c = 0;
+  if (live) {
+    const int h = (int)(row % H), bc = (int)(row / H);
+    c = bc % 3;
+    b = bc / 3;
+    const FParams p = load_params(params, b);
+    const float Ac = A ? A[b * 3 + c] : 0.8f;
+    const float* xr = x + row * W;
+    const float* ir = IcA ? IcA + ((long)b * H + h) * W : nullptr;
+    const float* gr = ds4 + row * W;
+    float* dxr = dx ? dx + row * W : nullptr;
+    float lraw;
+    const float lum = row_lum(xr, ir, Ac, p, c, lane, W, &lraw);
+    const float PI = 3.14159265358979323846f;
+    const float cl = -cosf(PI * lum) * 0.5f + 0.5f;
+    const float q = cl / (lum + 1e-6f);
+    const float K = (1.f - p.alpha) + p.alpha * q;
+    // every pixel with d3 = d4 * K; the three pixels that feed `lum` get their extra term afterwards
+    PwAcc acc = {0.f, 0.f, 0.f};
+    float dK = 0.f;
+    for (int w = lane; w < W; w += 64) {
+      const float I = ir ? ir[w] : 0.5f, xv = xr[w], g4 = gr[w];
+      const Px px = chain_px(xv, Ac, I, p, c);
+      dK += g4 * px.s3;
+      const float g = chain_bwd_px(px, xv, Ac, I, g4 * K, p, c, acc);
+      if (dxr) dxr[w] = accumulate ? dxr[w] + g : g;
+    }
+    dK = wave_sum(dK);
+    t_alpha = dK * (q - 1.f);
+    // d q / d lum, gated by clamp(lum, 0, 1) (inclusive bounds pass the gradient, as torch.clamp does)
+    float dlum = 0.f;
+    if (lraw >= 0.f && lraw <= 1.f) {
+      const float dcl = 0.5f * PI * sinf(PI * lum);
+      dlum = dK * p.alpha * (dcl * (lum + 1e-6f) - cl) / ((lum + 1e-6f) * (lum + 1e-6f));
+    }
+    if (lane < 3 && lane < W) {
+      const float coef = lane == 0 ? 0.27f : (lane == 1 ? 0.67f : 0.06f);
+      const float I = ir ? ir[lane] : 0.5f, xv = xr[lane];
+      const Px px = chain_px(xv, Ac, I, p, c);
+      const float g = chain_bwd_px(px, xv, Ac, I, coef * dlum, p, c, acc);
+      if (dxr) dxr[lane] += g;                                        // same lane wrote dxr[lane] in the loop above
+    }
+    t_om = wave_sum(acc.om);
+    t_wb = wave_sum(acc.wb);
+    t_gamma = wave_sum(acc.gamma);
   }
-  // phase 2
-  float a_gamma = 0.f, a_wb = 0.f, a_om = 0.f;
-  float* dxr = dx + (long)row * W;
-  for (int w = threadIdx.x; w < W; w += blockDim.x) {
-    float I = ir ? ir[w] : 0.5f;
-    float s1, s2;
-    float s3 = chain_s3(xr[w], Ac, I, p, c, &s1, &s2);
-    float d3 = gr[w] * K;
-    if (w == 0) d3 += 0.27f * dlum;
-    else if (w == 1) d3 += 0.67f * dlum;
-    else if (w == 2) d3 += 0.06f * dlum;
-    float base = fmaxf(s2, 1e-4f);
-    a_gamma += d3 * s3 * logf(base);
-    float d2 = (s2 >= 1e-4f) ? d3 * p.gamma * powf(base, p.gamma - 1.f) : 0.f;
-    a_wb += d2 * s1;
-    float d1 = d2 * p.s[c];
-    float txr = 1.f - p.omega * I;
-    float tx = fmaxf(txr, 0.01f);
-    if (txr >= 0.01f) a_om += d1 * (xr[w] - Ac) * I / (tx * tx);
-    float g = d1 / tx;
-    if (dx) dxr[w] = accumulate ? dxr[w] + g : g;
-  }
-  a_gamma = block_sum(a_gamma, sm);
-  a_wb = block_sum(a_wb, sm);
-  a_om = block_sum(a_om, sm);
-  if (threadIdx.x == 0) {
+  if (merged) {
+    if (lane == 0) {
+      s_part[wave][0] = t_om; s_part[wave][1] = t_wb; s_part[wave][2] = t_gamma; s_part[wave][3] = t_alpha;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && (long)blockIdx.x * PW_ROWS < (long)B * 3 * H) {
+      const int bc0 = (int)(((long)blockIdx.x * PW_ROWS) / H);
+      const int k = threadIdx.x;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < PW_ROWS; ++r) v += s_part[r][k];
+      float* dp = dparams + (bc0 / 3) * 8;
+      atomic_add_f32(dp + (k == 0 ? 0 : (k == 1 ? 1 + bc0 % 3 : (k == 2 ? 4 : 5))), v);
+    }
+  } else if (live && lane == 0) {
     float* dp = dparams + b * 8;
-    atomic_add_f32(dp + 0, a_om);
-    atomic_add_f32(dp + 1 + c, a_wb);
-    atomic_add_f32(dp + 4, a_gamma);
-    atomic_add_f32(dp + 5, d_alpha);
+    atomic_add_f32(dp + 0, t_om);
+    atomic_add_f32(dp + 1 + c, t_wb);
+    atomic_add_f32(dp + 4, t_gamma);
+    atomic_add_f32(dp + 5, t_alpha);
   }
-}
-
-// ---- USM: separable gaussian through LDS ----------------------------------------------------------------------------
-constexpr int TH = 16, TW = 64;
-constexpr int LH = TH + 2 * R, LW = TW + 2 * R;
-
-__device__ inline int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
-
-template <typename T>
-__global__ __launch_bounds__(256) void usm_fwd_kernel(const float* __restrict__ s4, const float* __restrict__ params,
-                                                       float* __restrict__ out, T* __restrict__ out8, float* __restrict__ hp,
-                                                       int B, int H, int W) {
-  __shared__ float tile[LH][LW + 1];
-  __shared__ float tmp[LH][TW + 1];
-  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const float lam = params[b * 8 + 6];
-  float res[3][4];
-  for (int c = 0; c < 3; ++c) {
-    const float* pl = s4 + ((long)b * 3 + c) * H * W;
-    __syncthreads();
-    for (int i = tid; i < LH * LW; i += 256) {
-      int r = i / LW, q = i - r * LW;
-      int yy = reflect(y0 + r - R, H), xx = reflect(x0 + q - R, W);
-      yy = min(max(yy, 0), H - 1);
-      xx = min(max(xx, 0), W - 1);
-      tile[r][q] = pl[(long)yy * W + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < LH * TW; i += 256) {
-      int r = i / TW, q = i - r * TW;
-      float a = c_taps[0] * tile[r][q + R];
-#pragma unroll
-      for (int d = 1; d <= R; ++d) a += c_taps[d] * (tile[r][q + R - d] + tile[r][q + R + d]);
-      tmp[r][q] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r = ty + 4 * j;
-      float a = c_taps[0] * tmp[r + R][tx];
-#pragma unroll
-      for (int d = 1; d <= R; ++d) a += c_taps[d] * (tmp[r + R - d][tx] + tmp[r + R + d][tx]);
-      float v = tile[r + R][tx + R];
-      float hi = v - a;
-      float o = hi * lam + v;
-      res[c][j] = o;
-      int yy = y0 + r, xx = x0 + tx;
-      if (yy < H && xx < W) {
-        long idx = (((long)b * 3 + c) * H + yy) * W + xx;
-        if (out) out[idx] = o;
-        if (hp) hp[idx] = hi;
-      }
-    }
-  }
-  if (out8) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int yy = y0 + ty + 4 * j, xx = x0 + tx;
-      if (yy < H && xx < W) {
-        float v[8] = {res[0][j], res[1][j], res[2][j], 0.f, 0.f, 0.f, 0.f, 0.f};
-        T* o = out8 + (((long)b * H + yy) * W + xx) * 8;
-        if constexpr (sizeof(T) == 4) {
-          stvec<T>(o, v);
-          stvec<T>(o + 4, v + 4);
-        } else {
-          stvec<T>(o, v);
-        }
-      }
-    }
-  }
-}
-
-// adjoint weight of the reflect-padded blur along one axis: d(blur[i]) / d(s[m]) for i = m + d
-// `taps` must point to LDS: the index differs per lane, and a divergent index into __constant__ memory is executed as a
-// waterfall loop over the distinct values (this made the first version of usm_bwd 10x slower than usm_fwd).
-__device__ inline float adj_w(const float* taps, int m, int d, int n) {
-  int ad = d < 0 ? -d : d;
-  float w = taps[ad];
-  if (m >= 1 && m <= R) {
-    int t = 2 * m + d;
-    t = t < 0 ? -t : t;
-    if (t <= R) w += taps[t];
-  }
-  if (m >= n - 1 - R && m <= n - 2) {
-    int t = 2 * (n - 1) - 2 * m - d;
-    t = t < 0 ? -t : t;
-    if (t <= R) w += taps[t];
-  }
-  return w;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
-                                                       const float* __restrict__ hp, const float* __restrict__ params,
-                                                       float* __restrict__ ds4, float* dparams, int B, int H, int W) {
-  // all three channels of the tile are staged at once: one 16-byte load per pixel of the NHWC gradient instead of three
-  // 2-byte loads at a 16-byte stride (the first version of this kernel spent 3.6 ms there)
-  __shared__ float tile[3][LH][LW + 1];
-  __shared__ float tmp[LH][TW + 1];
-  __shared__ float sm[20];
-  __shared__ float s_taps[R + 1];
-  if (threadIdx.x <= R) s_taps[threadIdx.x] = c_taps[threadIdx.x];
-  constexpr int VE = DT<T>::VE;
-  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const float lam = params[b * 8 + 6];
-  float dl = 0.f;
-  for (int i = tid; i < LH * LW; i += 256) {
-    int r = i / LW, q = i - r * LW;
-    int yy = y0 + r - R, xx = x0 + q - R;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      if (dout) {
-        const float* pl = dout + (((long)b * 3) * H + yy) * W + xx;
-        v0 = pl[0]; v1 = pl[(long)H * W]; v2 = pl[2L * H * W];
-      } else if (ld8 == VE) {
-        float v[VE];
-        ldvec<T>(dout8 + (((long)b * H + yy) * W + xx) * VE, v);
-        v0 = v[0]; v1 = v[1]; v2 = v[2];
-      } else {
-        const T* pp = dout8 + (((long)b * H + yy) * W + xx) * ld8;
-        v0 = DT<T>::ld(pp); v1 = DT<T>::ld(pp + 1); v2 = DT<T>::ld(pp + 2);
-      }
-    }
-    tile[0][r][q] = v0; tile[1][r][q] = v1; tile[2][r][q] = v2;
-  }
-  __syncthreads();
-  for (int c = 0; c < 3; ++c) {
-    for (int i = tid; i < LH * TW; i += 256) {
-      int r = i / TW, q = i - r * TW;
-      int m = x0 + q;
-      float a = 0.f;
-      if (m < W) {
-        const bool border = (m <= R) || (m >= W - 1 - R);
-        if (!border) {
-          a = c_taps[0] * tile[c][r][q + R];
-#pragma unroll
-          for (int d = 1; d <= R; ++d) a += c_taps[d] * (tile[c][r][q + R - d] + tile[c][r][q + R + d]);
-        } else {
-          for (int d = -R; d <= R; ++d) a += adj_w(s_taps, m, d, W) * tile[c][r][q + R + d];
-        }
-      }
-      tmp[r][q] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r = ty + 4 * j;
-      int m = y0 + r, xx = x0 + tx;
-      if (m < H && xx < W) {
-        float a = 0.f;
-        const bool border = (m <= R) || (m >= H - 1 - R);
-        if (!border) {
-          a = c_taps[0] * tmp[r + R][tx];
-#pragma unroll
-          for (int d = 1; d <= R; ++d) a += c_taps[d] * (tmp[r + R - d][tx] + tmp[r + R + d][tx]);
-        } else {
-          for (int d = -R; d <= R; ++d) a += adj_w(s_taps, m, d, H) * tmp[r + R + d][tx];
-        }
-        float g = tile[c][r + R][tx + R];
-        long idx = (((long)b * 3 + c) * H + m) * W + xx;
-        ds4[idx] = g * (1.f + lam) - lam * a;
-        dl += g * hp[idx];
-      }
-    }
-    __syncthreads();
-  }
-  dl = block_sum(dl, sm);
-  if (tid == 0) atomic_add_f32(dparams + b * 8 + 6, dl);
-}
-
-bool g_taps_ready = false;
-int ensure_taps() {
-  if (g_taps_ready) return 0;
-  float k[2 * R + 1];
-  float sum = 0.f;
-  for (int i = -R; i <= R; ++i) {
-    float xv = (float)i / 5.0f;
-    k[i + R] = expf(-0.5f * (xv * xv));
-    sum += k[i + R];
-  }
-  float taps[R + 1];
-  for (int d = 0; d <= R; ++d) taps[d] = k[R + d] / sum;
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_taps), taps, sizeof(taps));
-  if (e != hipSuccess) {
-    dy_set_error("frontend: hipMemcpyToSymbol failed: %s", hipGetErrorString(e));
-    return 3;
-  }
-  g_taps_ready = true;
-  return 0;
 }
 
 inline int ew_blocks(long total) {
@@ -436,8 +273,6 @@ inline int ew_blocks(long total) {
 }
 
 }  // namespace
-
-extern "C" int dy_frontend_init(void) { return ensure_taps(); }
 
 extern "C" int dy_image_to_nhwc8(const float* x, int B, int H, int W, void* y, int Ho, int Wo, int dtype, void* stream) {
   DY_CHECK(x && y && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dy_image_to_nhwc8: bad args");
@@ -472,7 +307,7 @@ extern "C" int dy_filter_params_bwd(const float* feat, int feat_ld, const float*
 extern "C" int dy_filters_pointwise_fwd(const float* x, const float* params, const float* A, const float* IcA, float* s4, int B,
                                         int H, int W, void* stream) {
   DY_CHECK(x && params && s4 && B > 0 && H > 0 && W >= 3, "dy_filters_pointwise_fwd: bad args (W must be >= 3)");
-  pointwise_fwd_kernel<<<B * 3 * H, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, s4, B, H, W);
+  pointwise_fwd_kernel<<<dy_cdiv((long)B * 3 * H, PW_ROWS), 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, s4, B, H, W);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -481,34 +316,7 @@ extern "C" int dy_filters_pointwise_bwd(const float* x, const float* params, con
                                         const float* ds4, float* dx, float* dparams, int B, int H, int W, int accumulate,
                                         void* stream) {
   DY_CHECK(x && params && ds4 && dparams && B > 0 && H > 0 && W >= 3, "dy_filters_pointwise_bwd: bad args");
-  pointwise_bwd_kernel<<<B * 3 * H, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, ds4, dx, dparams, B, H, W, accumulate);
-  DY_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int dy_usm_fwd(const float* s4, const float* params, float* out_nchw, void* out_nhwc8, float* hp, int B, int H, int W,
-                          int dtype, void* stream) {
-  DY_CHECK(s4 && params && B > 0, "dy_usm_fwd: bad args");
-  DY_CHECK(H > R && W > R, "dy_usm_fwd: reflect padding needs H, W > %d", R);
-  if (int e = ensure_taps()) return e;
-  dim3 grid(dy_cdiv(W, TW), dy_cdiv(H, TH), B);
-  if (dtype == DY_F32) usm_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(s4, params, out_nchw, (float*)out_nhwc8, hp, B, H, W);
-  else usm_fwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(s4, params, out_nchw, (bf16_t*)out_nhwc8, hp, B, H, W);
-  DY_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc8, int dout_ld, const float* hp, const float* params,
-                          float* ds4, float* dparams, int B, int H, int W, int dtype, void* stream) {
-  DY_CHECK(dout_nhwc8 == nullptr || dout_ld >= 3, "dy_usm_bwd: bad dout_ld");
-  DY_CHECK((dout_nchw != nullptr) != (dout_nhwc8 != nullptr), "dy_usm_bwd: exactly one of dout_nchw / dout_nhwc8");
-  DY_CHECK(hp && params && ds4 && dparams && B > 0 && H > R && W > R, "dy_usm_bwd: bad args");
-  if (int e = ensure_taps()) return e;
-  dim3 grid(dy_cdiv(W, TW), dy_cdiv(H, TH), B);
-  if (dtype == DY_F32)
-    usm_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(dout_nchw, (const float*)dout_nhwc8, dout_ld, hp, params, ds4, dparams, B, H, W);
-  else
-    usm_bwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(dout_nchw, (const bf16_t*)dout_nhwc8, dout_ld, hp, params, ds4, dparams, B, H, W);
+  pointwise_bwd_kernel<<<dy_cdiv((long)B * 3 * H, PW_ROWS), 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, ds4, dx, dparams, B, H, W, accumulate);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -454,6 +454,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
             raise RuntimeError("conv_backward: dx_out view too narrow")
     d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
                    None, accumulate, dtype)
+    d.dst_valid_channels = Cin
     _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                 bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)

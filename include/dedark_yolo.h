@@ -56,6 +56,8 @@ typedef struct {
   int KHf, KWf;           /* tap subset: `w` is a [Cd][KHf][KWf][Cs] pack and window tap (th, tw) of the KH x KW window uses */
   int kh0, kh_step;       /* weight tap (kh0 + kh_step*th, kw0 + kw_step*tw).  KHf == 0: no subset.  dy_conv2d_dgrad uses   */
   int kw0, kw_step;       /* this internally to run a stride-2 data gradient as 4 dense stride-1 problems (one per parity)   */
+  int dst_valid_channels; /* hint: only the first k destination channels can be non-zero (the rest is channel padding whose
+                             weights are zero); 0 = unknown.  Lets the stem kernels skip the padding. */
 } dy_conv_desc;
 
 /* forward: dst[n,ho,wo,:] = epilogue( sum_{kh,kw,c} src[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * w[:,kh,kw,c] ) */
