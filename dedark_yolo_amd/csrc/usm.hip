@@ -102,7 +102,7 @@ __device__ inline void vpass4(const float* __restrict__ tmp, int G, int lane, in
 }
 
 template <typename T>
-__global__ __launch_bounds__(NTH) void usm_fwd_kernel(const float* __restrict__ s4, const float* __restrict__ params,
+__global__ __launch_bounds__(NTH, 4) void usm_fwd_kernel(const float* __restrict__ s4, const float* __restrict__ params,
                                                        float* __restrict__ out, T* __restrict__ out8, float* __restrict__ hp, int B,
                                                        int H, int W) {
   __shared__ float tileT[LW * PT];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTH) void usm_fwd_kernel(const float* __restrict__ 
 }
 
 template <typename T>
-__global__ __launch_bounds__(NTH) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
+__global__ __launch_bounds__(NTH, 4) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
                                                        const float* __restrict__ hp, const float* __restrict__ params,
                                                        float* __restrict__ ds4, float* dparams, int B, int H, int W) {
   __shared__ float tileT[LW * PT];
