@@ -21,6 +21,11 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
 // band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
 int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
+// pipelined bf16 weight gradient (wgrad_v2.hip)
+bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, long x_ld, long dz_ld);
+int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
+                       int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
+                       long scratch_elems, float* g_oihw, void* stream);
 // direct stem kernels (conv_small.hip)
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
 int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream);
@@ -800,6 +805,9 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   DY_CHECK(((uintptr_t)x) % 16 == 0 && ((uintptr_t)dz) % 16 == 0, "dy_conv2d_wgrad: pointer not 16-byte aligned");
   const int ho = (Hi + 2 * pad - dil * (KH - 1) - 1) / stride + 1, wo = (Wi + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   DY_CHECK(ho == Ho && wo == Wo, "dy_conv2d_wgrad: dz %dx%d does not match conv output %dx%d", Ho, Wo, ho, wo);
+  if (dy_wgrad_v2_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, x_ld, dz_ld))
+    return dy_wgrad_v2_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
+                              scratch_elems, g_oihw, stream);
   WgP p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
   p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout_pad;

@@ -126,6 +126,12 @@ if __name__ == "__main__":
             conv_case(dt, 2, 64, 128, 40, 40, 3, 1, 1)
             conv_case(dt, 3, 128, 64, 32, 32, 3, 2, 1)
             conv_case(dt, 2, 64, 128, 65, 63, 3, 2, 1)  # parity-split dgrad on the pipelined kernel (strided destination)
+            # shapes routed to the pipelined weight-gradient kernel (wgrad_v2.hip): M >= 4096, Cout >= 64, K >= 128
+            conv_case(dt, 3, 64, 128, 40, 40, 3, 1, 1)
+            conv_case(dt, 8, 96, 80, 37, 41, 3, 1, 1)   # ragged k' and co tiles
+            conv_case(dt, 16, 64, 128, 40, 40, 3, 2, 1)
+            conv_case(dt, 4, 64, 64, 40, 40, 3, 1, 3, 3)  # dilation 3 (RFB)
+            conv_case(dt, 2, 384, 256, 48, 48, 1, 1, 0)
             conv_case(dt, 2, 256, 192, 48, 48, 1, 1, 0)
             conv_case(dt, 1, 64, 64, 50, 47, 3, 1, 1)
             conv_case(dt, 2, 192, 320, 24, 24, 3, 1, 1)
