@@ -663,7 +663,7 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st) {
 }
 
 int check_conv(const dy_conv_desc* d, const char* who) {
-  DY_CHECK(d && d->src && d->w && d->dst, "%s: null pointer", who);
+  DY_CHECK(d && d->src && d->w && (d->dst || d->dst_planar), "%s: null pointer", who);
   DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16, "%s: bad dtype %d", who, d->dtype);
   const int ve = d->dtype == DY_F32 ? 4 : 8, es = d->dtype == DY_F32 ? 4 : 2;
   DY_CHECK(d->Cs > 0 && d->Cs % ve == 0, "%s: Cs=%d must be a positive multiple of %d", who, d->Cs, ve);
@@ -698,6 +698,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
   DY_CHECK(d->KHf == 0 && d->dst_row_stride == 0, "dy_conv2d_dgrad: tap subsets / strided destinations are forward-only");
   if (dy_conv_small_dgrad_eligible(d)) return dy_conv_small_dgrad_launch(d, stream);
+  DY_CHECK(d->dst_planar == nullptr, "dy_conv2d_dgrad: dst_planar is only supported by the direct stem kernel (bf16, 3x3 s2 p1, Cd == 8)");
   static const bool no_parity = getenv("DY_NO_PARITY_DGRAD") != nullptr;
   if (d->stride == 2 && d->dil == 1 && !no_parity) {
     // Stride-2 data gradient = 4 independent dense problems, one per parity class (ph, pw) of the output pixel: only the

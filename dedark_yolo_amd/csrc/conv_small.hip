@@ -23,7 +23,7 @@ template <int CS, int NCI>
 __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __restrict__ dz, long dz_ld,
                                                                 const uint32_t* __restrict__ wt, bf16_t* __restrict__ dx,
                                                                 long dx_ld, int N, int Hd, int Wd, int Hs, int Ws,
-                                                                int accumulate) {
+                                                                int accumulate, bf16_t* __restrict__ planar, int nplanes) {
   constexpr int NP = CS / 2;                         // packed pairs per pixel
   const int QH = (Hd + 1) >> 1, QW = (Wd + 1) >> 1;
   const long q = blockIdx.x * 256L + threadIdx.x;
@@ -72,6 +72,27 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
         acc[dh][dw][ci] = s;
       }
 
+  if (planar) {
+    // planar [N, nplanes, Hd, Wd] output (the front-end's layout): 6 B per pixel instead of the 16 B NHWC8 vector
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+      const int h = 2 * qh + dh;
+      if (h >= Hd) continue;
+#pragma unroll
+      for (int ci = 0; ci < NCI; ++ci) {
+        if (ci >= nplanes) break;
+        bf16_t* o = planar + (((long)n * nplanes + ci) * Hd + h) * Wd + 2 * qw;
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw)
+          if (2 * qw + dw < Wd) {
+            float v = acc[dh][dw][ci];
+            if (accumulate) v += bf16_to_f32(o[dw]);
+            o[dw] = f32_to_bf16(v);
+          }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -90,6 +111,41 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
     }
 }
 
+// dgrad of a 1x1 convolution with 8 (padded) output channels -- the ASFF weight_level convs Conv(c, 8, 1) of
+// ultralytics/nn/modules/block.py:47-52:  dx[m][ci] (+)= sum_{co<8} dz[m][co] * w[co][ci].  Pure write bandwidth; the MFMA
+// tile kernel spent 525 us on 64x80x80x256 (K = 8 of a 64-wide step, 2-byte stores), this one moves 16 B per lane.
+constexpr int THIN_PX = 4;
+__global__ __launch_bounds__(256) void dgrad1x1_thin_kernel(const bf16_t* __restrict__ dz, long dz_ld, const bf16_t* __restrict__ wt,
+                                                             bf16_t* __restrict__ dx, long dx_ld, long M, int Cd, int accumulate) {
+  const int CG = Cd >> 3;
+  const long t = blockIdx.x * 256L + threadIdx.x;
+  const int cg = (int)(t % CG);
+  const long m0 = (t / CG) * THIN_PX;
+  if (m0 >= M) return;
+  u32x4 w[8];                                        // rows ci = 8*cg + e of the [Cd][8] transposed pack
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const u32x4*>(wt + ((long)cg * 8 + e) * 8);
+#pragma unroll
+  for (int px = 0; px < THIN_PX; ++px) {
+    const long m = m0 + px;
+    if (m >= M) break;
+    const u32x4 z = *reinterpret_cast<const u32x4*>(dz + m * dz_ld);
+    bf16_t* o = dx + m * dx_ld + cg * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (accumulate) ldvec<bf16_t>(o, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = v[e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s = dot2(z[q], w[e][q], s);
+      v[e] = s;
+    }
+    stvec<bf16_t>(o, v);
+  }
+}
+
 template <int CS>
 int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
   const long quads = (long)d->N * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
@@ -97,7 +153,8 @@ int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
   const int nci = d->dst_valid_channels > 0 && d->dst_valid_channels <= 4 ? 4 : 8;
 #define GO(NCI)                                                                                                              \
   dgrad3x3s2_small_kernel<CS, NCI><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const uint32_t*)d->w, (bf16_t*)d->dst, \
-                                                         d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate)
+                                                         d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate,        \
+                                                         (bf16_t*)d->dst_planar, d->dst_valid_channels)
   if (nci == 4) GO(4); else GO(8);
 #undef GO
   DY_LAUNCH_CHECK();
@@ -106,16 +163,31 @@ int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
 
 }  // namespace
 
+static bool thin_eligible(const dy_conv_desc* d) {
+  return d->dtype == DY_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cs == 8 && d->Cd % 8 == 0 &&
+         d->KHf == 0 && d->dst_row_stride == 0 && d->dst && !d->dst_planar && (d->src_ld * 2) % 16 == 0 && (d->dst_ld * 2) % 16 == 0 &&
+         d->Hs == d->Hd && d->Ws == d->Wd;
+}
+
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d) {
   static const bool off = getenv("DY_NO_CONV_SMALL") != nullptr;
   if (off) return false;
+  if (thin_eligible(d)) return true;
   return d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1 && d->Cd == 8 &&
          (d->Cs == 16 || d->Cs == 32 || d->Cs == 64) && d->KHf == 0 && d->dst_row_stride == 0 && (d->src_ld * 2) % 16 == 0 &&
-         (d->dst_ld * 2) % 16 == 0;
+         ((d->dst_planar && d->dst_valid_channels > 0 && d->dst_valid_channels <= 8) || (d->dst && (d->dst_ld * 2) % 16 == 0));
 }
 
 int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (thin_eligible(d)) {
+    const long M = (long)d->N * d->Hd * d->Wd;
+    const long threads = (M + THIN_PX - 1) / THIN_PX * (d->Cd / 8);
+    dgrad1x1_thin_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const bf16_t*)d->w,
+                                                                           (bf16_t*)d->dst, d->dst_ld, M, d->Cd, d->accumulate);
+    DY_LAUNCH_CHECK();
+    return 0;
+  }
   if (d->Cs == 16) return launch_small_dgrad<16>(d, st);
   if (d->Cs == 32) return launch_small_dgrad<32>(d, st);
   return launch_small_dgrad<64>(d, st);

@@ -36,7 +36,8 @@ __device__ inline int reflect(int i, int n) {
 // element of staged sample 0 (image coordinate o0 - R), consecutive samples are `pitch` floats apart.
 //   m = 0:            - sum_{i=1..R} k[i] g[i]          1 <= m <= R:          + k[m] g[0]
 //   m = n-1:          - sum_{i=1..R} k[i] g[n-1-i]      n-1-R <= m <= n-2:    + k[n-1-m] g[n-1]
-__device__ inline float adj_edge(const float* line, int pitch, int m, int o0, int n) {
+// (not inlined: inlining it four times per pass pushed usm_bwd to 224 VGPRs / scratch spills that tripled its HBM traffic)
+__device__ __noinline__ float adj_edge(const float* line, int pitch, int m, int o0, int n) {
   float c = 0.f;
   if (m == 0) {
     for (int i = 1; i <= R; ++i) c -= c_taps[i] * line[(i - o0 + R) * pitch];
@@ -192,6 +193,8 @@ __global__ __launch_bounds__(NTH, 4) void usm_bwd_kernel(const float* __restrict
       float v;
       if (dout) {
         v = dout[(((long)b * 3 + c) * H + yy) * W + xx];
+      } else if (ld8 == 0) {                                   // planar [B,3,H,W] in the compute dtype (direct stem dgrad)
+        v = DT<T>::ld(dout8 + (((long)b * 3 + c) * H + yy) * W + xx);
       } else if (ld8 == VE) {
         float t[VE];
         ldvec<T>(dout8 + (((long)b * H + yy) * W + xx) * VE, t);
@@ -267,7 +270,7 @@ extern "C" int dy_usm_fwd(const float* s4, const float* params, float* out_nchw,
 
 extern "C" int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc8, int dout_ld, const float* hp, const float* params,
                           float* ds4, float* dparams, int B, int H, int W, int dtype, void* stream) {
-  DY_CHECK(dout_nhwc8 == nullptr || dout_ld >= 3, "dy_usm_bwd: bad dout_ld");
+  DY_CHECK(dout_nhwc8 == nullptr || dout_ld >= 3 || dout_ld == 0, "dy_usm_bwd: bad dout_ld");
   DY_CHECK((dout_nchw != nullptr) != (dout_nhwc8 != nullptr), "dy_usm_bwd: exactly one of dout_nchw / dout_nhwc8");
   DY_CHECK(hp && params && ds4 && dparams && B > 0 && H > R && W > R, "dy_usm_bwd: bad args");
   if (int e = ensure_taps()) return e;

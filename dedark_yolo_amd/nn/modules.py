@@ -585,10 +585,14 @@ class lowlight_recovery(DyModule):
         B, _, H, W = x.shape
         dev, f32, st = x.device, torch.float32, stream()
         need_dx = bool(needs[0])
-        ops.padded_channels(dout)               # raises unless dout is a zero-padded NHWC view
         dparams = torch.zeros((B, 8), dtype=f32, device=dev)
         ds4 = torch.empty((B, 3, H, W), dtype=f32, device=dev)
-        call("dy_usm_bwd", None, ptr(dout), ld_of(dout), ptr(hp), ptr(params), ptr(ds4), ptr(dparams), B, H, W,
+        if dout.is_contiguous() and dout.shape[1] == 3:       # planar gradient from the direct stem dgrad kernel
+            dld = 0
+        else:
+            ops.padded_channels(dout)           # raises unless dout is a zero-padded NHWC view
+            dld = ld_of(dout)
+        call("dy_usm_bwd", None, ptr(dout), dld, ptr(hp), ptr(params), ptr(ds4), ptr(dparams), B, H, W,
              ops.dt_id(dout.dtype), st)
         dx = torch.empty((B, 3, H, W), dtype=f32, device=dev) if need_dx else None
         call("dy_filters_pointwise_bwd", ptr(x), ptr(params), ptr(s["A"]), ptr(s["I"]), ptr(ds4), ptr(dx), ptr(dparams), B, H, W, 0, st)

@@ -5,6 +5,7 @@ Tensor convention between modules: logical shape [B, C, H, W] (the reference's m
 legal input/output ("view" = pointer + pixel stride), which is how C2f / SPPF / Detect concats cost nothing.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -242,7 +243,10 @@ def _conv_desc(src, w, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, KH, KW, stride, pad, dil,
     d.src, d.src_ld = src.data_ptr(), ld_of(src)
     d.N, d.Hs, d.Ws, d.Cs = N, Hs, Ws, Cs
     d.w = w.data_ptr()
-    d.dst, d.dst_ld = dst.data_ptr(), ld_of(dst)
+    if dst is not None:
+        d.dst, d.dst_ld = dst.data_ptr(), ld_of(dst)
+    else:                                   # dgrad into a planar tensor (dst_planar is set by the caller)
+        d.dst, d.dst_ld = None, Cd
     d.Hd, d.Wd, d.Cd = Hd, Wd, Cd
     d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
     d.scale, d.shift = ptr(scale), ptr(shift)
@@ -445,6 +449,20 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     if not need_dx:
         return None
     wt = _pack(ctx.weight, cout_pad, cin_pad, True, dtype)
+    # network stem (3 -> c, 3x3 stride 2): the direct kernel writes dx planar [B,Cin,H,W], the layout the front-end's
+    # backward consumes (6 B/pixel instead of a 16 B NHWC8 vector that is 5/8 padding)
+    planar = (dx_out is None and dtype == torch.bfloat16 and cin_pad == 8 and Cin <= 4 and (KH, KW) == (3, 3) and ctx.stride == 2
+              and ctx.pad == 1 and ctx.dil == 1 and cout_pad in (16, 32, 64) and os.environ.get("DY_NO_CONV_SMALL") is None)
+    if planar:
+        dxp = torch.empty((B, Cin, H, W), dtype=dtype, device=dev)
+        d = _conv_desc(dz, wt, None, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
+                       None, False, dtype)
+        d.dst_valid_channels = Cin
+        d.dst_planar = dxp.data_ptr()
+        _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W} (planar)", dtype=str(dtype),
+                    flops=2.0 * pixels * Cout * KH * KW * Cin, bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size()))
+        call("dy_conv2d_dgrad", C.byref(d), st)
+        return dxp
     if dx_out is None:
         dxb = empty_nhwc(B, cin_pad, H, W, dtype, dev)
         accumulate = False

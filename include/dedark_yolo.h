@@ -58,6 +58,9 @@ typedef struct {
   int kw0, kw_step;       /* this internally to run a stride-2 data gradient as 4 dense stride-1 problems (one per parity)   */
   int dst_valid_channels; /* hint: only the first k destination channels can be non-zero (the rest is channel padding whose
                              weights are zero); 0 = unknown.  Lets the stem kernels skip the padding. */
+  void* dst_planar;       /* dy_conv2d_dgrad only, optional: write dx as PLANAR [N, dst_valid_channels, Hd, Wd] (compute dtype)
+                             instead of the NHWC view `dst` (which may then be NULL).  Only the direct stem kernel (3x3,
+                             stride 2, pad 1, <= 8 padded input channels, bf16) supports it; otherwise the call fails. */
 } dy_conv_desc;
 
 /* forward: dst[n,ho,wo,:] = epilogue( sum_{kh,kw,c} src[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * w[:,kh,kw,c] ) */
@@ -163,7 +166,8 @@ int dy_filters_pointwise_fwd(const float* x, const float* params, const float* A
 int dy_usm_fwd(const float* s4, const float* params, float* out_nchw, void* out_nhwc8, float* hp, int B, int H, int W,
                int dtype, void* stream);
 /* USM backward: ds4 = dout*(1+lambda) - lambda*blur^T(dout); dparams[b,6] += sum dout*hp.  dout is either NCHW f32
- * (dout_nchw) or a padded NHWC view in `dtype` with pixel stride dout_ld (dout_nhwc); exactly one is non-NULL. */
+ * (dout_nchw) or, in `dtype`, a padded NHWC view with pixel stride dout_ld >= 3 / a planar [B,3,H,W] tensor when
+ * dout_ld == 0 (dout_nhwc); exactly one of the two pointers is non-NULL. */
 int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc, int dout_ld, const float* hp, const float* params, float* ds4,
                float* dparams, int B, int H, int W, int dtype, void* stream);
 /* pointwise backward: recomputes the chain from x, consumes ds4, writes dx (overwrite or +=; NULL = not needed) and

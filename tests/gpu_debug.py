@@ -132,6 +132,9 @@ if __name__ == "__main__":
             conv_case(dt, 16, 64, 128, 40, 40, 3, 2, 1)
             conv_case(dt, 4, 64, 64, 40, 40, 3, 1, 3, 3)  # dilation 3 (RFB)
             conv_case(dt, 2, 384, 256, 48, 48, 1, 1, 0)
+            conv_case(dt, 3, 256, 8, 37, 23, 1, 1, 0)     # thin 1x1 dgrad (ASFF weight_level convs)
+            conv_case(dt, 2, 3, 16, 64, 64, 3, 2, 1)      # stem: direct dot2 dgrad, planar dx
+            conv_case(dt, 2, 3, 64, 33, 47, 3, 2, 1)
             conv_case(dt, 2, 256, 192, 48, 48, 1, 1, 0)
             conv_case(dt, 1, 64, 64, 50, 47, 3, 1, 1)
             conv_case(dt, 2, 192, 320, 24, 24, 3, 1, 1)
