@@ -159,10 +159,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if os.environ.get("DY_SINGLE_DEVICE"):      # rehearsal of the N>1 code path on a one-GPU box (tests): every rank on cuda:0, gloo
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("DY_DIST_BACKEND", "nccl"))
 
     from dedark_yolo_amd.engine.trainer import DetectionTrainer, get_cfg
     from dedark_yolo_amd.nn.tasks import DetectionModel
@@ -209,6 +212,11 @@ def main():
                                     "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, inputs resident in HBM",
                            global_batch=args.batch * world, parallelism=f"dp{world}"),
                final_loss=round(final_loss, 4))
+    if world > 1:                                 # replicas must stay bit-identical: same start state, same summed gradients
+        h = trainer.flat.p.double().sum().reshape(1)
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        out["replicas_in_sync"] = bool(all(torch.equal(hs[0], t) for t in hs))
 
     if rank == 0 and not args.no_roofline:
         agg, psteps = kernel_profile(trainer, batches)

@@ -181,7 +181,7 @@ class DetectionTrainer:
         self.model.train()
         if self.world_size > 1:
             if not dist.is_initialized():
-                dist.init_process_group("nccl" if dist.is_nccl_available() else "gloo")
+                dist.init_process_group(os.environ.get("DY_DIST_BACKEND", "nccl" if dist.is_nccl_available() else "gloo"))
             for t in list(self.model.parameters()) + list(self.model.buffers()):       # K3: one broadcast of the start state
                 dist.broadcast(t.data, src=0)
         self.flat = FlatState(self.model, with_ema=True)

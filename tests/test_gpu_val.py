@@ -165,3 +165,31 @@ def test_validator_map_vs_oracle_on_product_predictions():
     assert abs(got["metrics/mAP50(B)"] - want50) <= 1e-4 and abs(got["metrics/mAP50-95(B)"] - want) <= 1e-4
     assert abs(got["metrics/precision(B)"] - r["p"].mean()) <= 1e-4 and abs(got["metrics/recall(B)"] - r["r"].mean()) <= 1e-4
     assert abs(got["fitness"] - oval.fitness(r["ap"])) <= 1e-4
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """Rehearsal of `bench.py --gpus 2` (the driver's multi-GPU launch line) on a one-GPU box: two ranks share cuda:0 and
+    all-reduce through gloo.  Checks the launch contract (one JSON line from rank 0, n_gpus, global batch), that the bucketed
+    all-reduce path runs from the backward hooks, and that the replicas stay bit-identical."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DY_SINGLE_DEVICE="1", DY_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--imgsz", "128", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
+    assert out["replicas_in_sync"] is True
+    assert np.isfinite(out["final_loss"]) and out["value"] > 0
