@@ -131,6 +131,19 @@ def kernel_profile(trainer, batches, steps=3):
     return agg, steps
 
 
+def pmc_traffic(args, kernel_class):
+    """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, separate passes); None when no summary exists for the workload."""
+    tag = workload_tag(args)
+    f = "r01_c2_pmc_traffic.json" if "configs[1]" in tag else ("r01_c3_pmc_traffic.json" if "configs[2]" in tag else None)
+    path = os.path.join(ROOT, "profiles", f) if f else None
+    if not path or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        c = json.load(fh).get("classes", {}).get(kernel_class.split("/")[0])
+    return round(c["traffic_bytes_per_call"]) if c else None
+
+
 def workload_tag(args):
     """Which BASELINE.json config the command line is (C2 = YOLOv8n + lowlight_recovery B=32, C3 = repo yolov8.yaml@L B=64)."""
     key = (os.path.basename(args.model), args.imgsz, args.batch, args.dtype)
@@ -235,7 +248,8 @@ def main():
             ach = a["bytes"] / a["n"] / avg_s / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
         roof.update(kernel=name, launches_per_step=a["n"] // psteps, avg_launch_us=round(avg_s * 1e6, 2),
-                    share_of_kernel_time=round(a["ms"] / tot, 3), flop_per_byte=round(intensity, 1), traffic=None)
+                    share_of_kernel_time=round(a["ms"] / tot, 3), flop_per_byte=round(intensity, 1),
+                    algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]), traffic=pmc_traffic(args, name))
         out["roofline"] = roof
         out["kernel_time_breakdown_ms_per_step"] = {k: round(v["ms"] / psteps, 3) for k, v in top[:10]}
     if world > 1:

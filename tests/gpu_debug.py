@@ -130,7 +130,8 @@ if __name__ == "__main__":
             conv_case(dt, 3, 64, 128, 40, 40, 3, 1, 1)
             conv_case(dt, 8, 96, 80, 37, 41, 3, 1, 1)   # ragged k' and co tiles
             conv_case(dt, 16, 64, 128, 40, 40, 3, 2, 1)
-            conv_case(dt, 4, 64, 64, 40, 40, 3, 1, 3, 3)  # dilation 3 (RFB)
+            conv_case(dt, 4, 128, 96, 40, 40, 3, 1, 3, 3)  # dilation 3 (RFB)
+            conv_case(dt, 9, 64, 64, 128, 128, 3, 1, 1)    # Cout 64: pipelined kernel only for long pixel loops (M >= 131072)
             conv_case(dt, 2, 384, 256, 48, 48, 1, 1, 0)
             conv_case(dt, 3, 256, 8, 37, 23, 1, 1, 0)     # thin 1x1 dgrad (ASFF weight_level convs)
             conv_case(dt, 2, 3, 16, 64, 64, 3, 2, 1)      # stem: direct dot2 dgrad, planar dx

@@ -1,0 +1,74 @@
+"""Raw conv kernels (forward, data gradient, weight gradient, bias gradient) against torch's own fp32 conv on the same
+GPU, per dispatch route of csrc/: generic implicit GEMM (f32 exact MFMA and bf16), pipelined v2, 3x3 band kernel v3,
+parity-split stride-2 dgrad, direct stem / thin kernels, pipelined weight gradient.  Inputs of the bf16 cases are rounded to
+bf16 before the reference runs, so the difference is output rounding and accumulation order only:
+tolerance 1e-5 * max|ref| (f32) and 1e-2 * max|ref| (bf16)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+class _Tape:
+    def __init__(self):
+        self.stack, self.pgrads = [], {}
+
+    def push(self, c):
+        self.stack.append(c)
+
+    def pop(self):
+        return self.stack.pop()
+
+
+def _err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _case(dtype, B, Cin, Cout, H, W, k, s, p, d=1):
+    from dedark_yolo_amd import ops
+    torch.manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, device="cuda")
+    w = (torch.randn(Cout, Cin, k, k, device="cuda") * (1.0 / (Cin * k * k) ** 0.5)).requires_grad_(True)
+    bias = torch.randn(Cout, device="cuda").requires_grad_(True)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    wq = w.detach().to(dtype).float().requires_grad_(True)
+    ref = F.conv2d(xr, wq, bias, s, p, d)
+    tape = _Tape()
+    y = ops.conv_forward(tape, ops.as_nhwc(x, dtype), w, bias, None, 0, s, p, d, False)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    dx = ops.conv_backward(tape, ops.as_nhwc(gy, dtype), need_dx=True)
+    # the reference saw gy in f32; the kernel saw it rounded to `dtype`: compare against a reference fed the rounded gy
+    xr2 = xr.detach().clone().requires_grad_(True)
+    wq2 = wq.detach().clone().requires_grad_(True)
+    b2 = bias.detach().clone().requires_grad_(True)
+    F.conv2d(xr2, wq2, b2, s, p, d).backward(gy.to(dtype).float())
+    torch.cuda.synchronize()
+    return dict(fwd=_err(y, ref), dx=_err(dx, xr2.grad), dw=_err(tape.pgrads[w], wq2.grad), db=_err(tape.pgrads[bias], b2.grad))
+
+
+GENERIC = [(1, 8, 32, 4, 4, 1, 1, 0), (2, 24, 16, 9, 7, 1, 1, 0), (2, 16, 32, 12, 20, 3, 2, 1), (2, 32, 64, 16, 16, 3, 1, 1),
+           (1, 64, 128, 20, 20, 3, 1, 1), (1, 32, 8, 10, 9, 3, 1, 2, 2), (2, 256, 256, 8, 8, 3, 1, 1), (2, 8, 16, 33, 31, 5, 1, 2),
+           (2, 16, 32, 13, 21, 3, 2, 1),      # stride-2 dgrad as 4 parity classes, odd sizes
+           (2, 8, 16, 12, 14, 1, 2, 0),       # k1 s2: empty parity classes -> masked fallback
+           (1, 8, 16, 17, 16, 5, 2, 2)]       # k5 s2: unequal class pads -> masked fallback
+PIPELINED = [(2, 64, 128, 40, 40, 3, 1, 1), (3, 128, 64, 32, 32, 3, 2, 1), (2, 64, 128, 65, 63, 3, 2, 1),
+             (2, 256, 192, 48, 48, 1, 1, 0), (1, 64, 64, 50, 47, 3, 1, 1), (2, 192, 320, 24, 24, 3, 1, 1),
+             (3, 64, 128, 40, 40, 3, 1, 1), (8, 96, 80, 37, 41, 3, 1, 1), (16, 64, 128, 40, 40, 3, 2, 1),
+             (4, 128, 96, 40, 40, 3, 1, 3, 3), (9, 64, 64, 128, 128, 3, 1, 1), (2, 384, 256, 48, 48, 1, 1, 0),
+             (3, 256, 8, 37, 23, 1, 1, 0),     # thin 1x1 dgrad (ASFF weight_level convs)
+             (2, 3, 16, 64, 64, 3, 2, 1), (2, 3, 64, 33, 47, 3, 2, 1)]   # stem: direct dot2 dgrad with planar dx
+
+
+@pytest.mark.parametrize("shape", GENERIC, ids=lambda s: "x".join(map(str, s)))
+def test_conv_f32_exact_mfma(shape):
+    r = _case(torch.float32, *shape)
+    assert max(r.values()) < 1e-5, r
+
+
+@pytest.mark.parametrize("shape", GENERIC + PIPELINED, ids=lambda s: "x".join(map(str, s)))
+def test_conv_bf16(shape):
+    r = _case(torch.bfloat16, *shape)
+    assert max(r.values()) < 1e-2, r
