@@ -1,0 +1,105 @@
+// Shared epilogue of the pipelined bf16 conv kernels (conv_v2.hip, conv_v3.hip): f32 accumulators -> affine + activation ->
+// bf16 tile in HBM with 16-byte stores, plus the per-channel (sum, sum of squares) of the RAW accumulators for BatchNorm.
+//
+// The 32x32 MFMA leaves lane (col = lane&31, half hh = lane>>5) with rows (r&3) + 8*(r>>2) + 4*hh of ONE column: four
+// consecutive registers are four consecutive ROWS.  The first version wrote a row-major [BM][BN] image with 64 two-byte
+// ds_write per lane (15.8 k cycles of a 108 k-cycle block, measured with s_memtime).  Here the image is stored TRANSPOSED,
+// imageT[col][row], so the four rows of a register quad are one 8-byte ds_write_b64 (16 per lane), and the store phase reads
+// it back with ds_read_b64_tr_b16: a 16-lane group fetches 4 channels x 16 pixels and every lane receives the 4 channels of
+// ITS pixel; two reads = the 16-byte (8-channel) vector of one pixel.  A wave covers 16 pixels x 32 channels per store
+// instruction (64 contiguous bytes per pixel).
+#pragma once
+#include "dy_common.h"
+
+namespace dy_epi {
+
+constexpr int PT = 520;      // bytes per imageT row (256 rows x 2 B + 8 B pad)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <int BN>
+constexpr int image_bytes() { return BN * PT; }
+
+__device__ inline uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+// BM must be 256 (PT), 8 waves as WM x WN = 4 x 2, wave tile 64 x (BN/2).  `off(m)` = element offset of output pixel m.
+template <int BN, int TM, int TN, typename OffFn>
+__device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int wn, int lane, int wave, long m0, int n0, long M, int Cd,
+                                  const float* scale, const float* shift, int act, int accumulate, bf16_t* dst, OffFn off,
+                                  float (&csum)[TN], float (&csq)[TN]) {
+  constexpr int BM = 256, WN = 2;
+  const int cl = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  __builtin_amdgcn_s_barrier();                   // every wave is done reading the ring
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / WN) + j * 32 + cl;
+    const int n = n0 + col;
+    const bool nok = n < Cd;
+    const float sc = (nok && scale) ? scale[n] : 1.f;
+    const float sf = (nok && shift) ? shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = wm * (BM / 4) + i * 32 + 4 * hh;
+      const long mrem = M - (m0 + row0);           // rows with (r&3)+8*(r>>2) < mrem are real pixels
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = acc[i][j][4 * rq + e];
+          if (nok && 8 * rq + e < mrem) {
+            csum[j] += a;
+            csq[j] += a * a;
+          }
+          float u = a * sc + sf;
+          if (act == DY_ACT_SILU) u = u * dy_sigmoid(u);
+          else if (act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
+          v[e] = u;
+        }
+        uint2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(smem + col * PT + (row0 + 8 * rq) * 2) = w;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- store phase: unit = 16 pixels x 32 channels per wave instruction
+  constexpr int UP = BM / 16, UC = BN / 32;
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int u = wave; u < UP * UC; u += 8) {
+    const int pt = u / UC, ct = u - pt * UC;
+    const int cb = ct * 32 + 8 * g;                // first channel of this lane's 8-channel vector
+    const char* base = smem + (cb + tq) * PT + (pt * 16 + 4 * tp) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 4 * PT));
+    const long m = m0 + pt * 16 + li;
+    const int n = n0 + cb;
+    if (m < M && n < Cd) {
+      u32x4 v;
+      v[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      v[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      v[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      v[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      bf16_t* o = dst + off(m) + n;
+      if (n + 8 <= Cd) {
+        if (accumulate) {
+          float x[8], y[8];
+          ldvec<bf16_t>(o, x);
+          ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += y[e];
+          stvec<bf16_t>(o, x);
+        } else {
+          *reinterpret_cast<u32x4*>(o) = v;
+        }
+      } else {                                     // ragged channel tail (never happens for padded views)
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+        for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+      }
+    }
+  }
+}
+
+}  // namespace dy_epi

@@ -12,6 +12,7 @@
 // Requirements (checked by the dispatcher): bf16, Cs % 64 == 0 (a K-step never straddles two taps), dense 16-byte aligned views.
 #include <stdlib.h>
 #include "dy_common.h"
+#include "conv_epilogue.h"
 #include "../../include/dedark_yolo.h"
 
 namespace v2 {
@@ -233,77 +234,14 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   }
 
   stamp(p.ablate, 5);
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // The accumulators go through LDS once ([BM][BN] bf16 image in the now idle ring) so that the HBM side is written with
-  // 16-byte vectors of 8 consecutive channels (the first version stored 2 bytes per lane and 64 addresses per lane: its
-  // epilogue cost as much as the whole K loop on the stage-3/4 shapes).
+  // ---- epilogue (conv_epilogue.h): accumulators -> transposed bf16 image in the idle ring -> 16-byte stores through
+  // ds_read_b64_tr_b16; csum / csq = per-column sums of the raw accumulators for the BatchNorm statistics below
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
-  __builtin_amdgcn_s_barrier();                   // every wave is done reading the ring
-  bf16_t* ct = reinterpret_cast<bf16_t*>(smem);   // [BM][BN]
-  const int act = p.act;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * (BN / WN) + j * 32 + cl;
-    const int n = n0 + col;
-    const bool nok = n < p.Cd;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sf = (nok && p.shift) ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row0 = wm * (BM / WM) + i * 32 + 4 * hh;
-      const long mrem = p.M - (m0 + row0);       // rows with (r&3)+8*(r>>2) < mrem are real pixels
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        float a = acc[i][j][r];
-        if (nok && dr < mrem) {
-          csum[j] += a;
-          csq[j] += a * a;
-        }
-        float v = a * sc + sf;
-        if (act == DY_ACT_SILU) v = v * dy_sigmoid(v);
-        else if (act == DY_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
-        ct[(row0 + dr) * BN + col] = f32_to_bf16(v);
-      }
-    }
-  }
-  __syncthreads();
+  if (!(p.ablate & 4))
+    dy_epi::store_tile<BN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
+                                   reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
   stamp(p.ablate, 6);
-  {
-    constexpr int VPR = BN / 8;                  // 16-byte vectors per tile row
-    constexpr int RPP = NT / VPR;                // rows per pass
-    const int vc = tid % VPR, vr = tid / VPR;
-    const int n = n0 + vc * 8;
-    bf16_t* dst = reinterpret_cast<bf16_t*>(p.dst);
-    if (n < p.Cd && !(p.ablate & 4)) {
-      const bool full = n + 8 <= p.Cd;
-#pragma unroll 4
-      for (int row = vr; row < BM; row += RPP) {
-        const long m = m0 + row;
-        if (m >= p.M) break;
-        u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * BN + vc * 8);
-        bf16_t* o = dst + dst_offset(p, m) + n;
-        if (full) {
-          if (p.accumulate) {
-            float x[8], y[8];
-            ldvec<bf16_t>(o, x);
-            ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += y[e];
-            stvec<bf16_t>(o, x);
-          } else {
-            *reinterpret_cast<u32x4*>(o) = v;
-          }
-        } else {                                 // ragged channel tail (Cd not a multiple of 8 never happens for padded views)
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int q = 0; q < 8 && n + q < p.Cd; ++q) o[q] = p.accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
-        }
-      }
-    }
-  }
   stamp(p.ablate, 7);
   if (p.stats) {
     __syncthreads();                              // the bf16 image has been consumed: reuse LDS for the column sums
