@@ -5,6 +5,7 @@
 // Thread mapping: a thread owns ONE 16-byte channel group for its whole life (per-channel constants live in registers) and
 // walks pixels with a grid stride, two pixels in flight per iteration; a wave covers 64 consecutive channel groups of one
 // pixel row (1 KiB contiguous when C >= 512 bf16) or several adjacent pixels for narrower tensors.
+#include <stdlib.h>
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
@@ -297,15 +298,29 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
 
 struct Geo { int cgb, rows; dim3 grid; };
 
-// ppt: pixels per thread the grid is sized for (more -> fewer blocks -> fewer atomics / less per-block prologue)
-Geo geometry(long pixels, int C, int ve, int ppt, int max_x) {
+// Grid policy (swept with tools/bn_bench on the YOLOv8-L shapes): every block pays a prologue proportional to the channels it
+// covers (per-channel constants; the backward kernels also fold DY_BN_BWD_REPLICAS x 2 doubles per channel) and the reduce
+// kernel ends with 2 atomics per channel, so wide tensors want FEWER, longer-running blocks: about 2^18 / C of them (2048 at
+// C <= 128 ... 512 at C = 512), never fewer than 4 pixels per thread.  E.g. apply on 512ch x 102,400 px: 6,400 blocks 118 us,
+// 1,024 blocks 82 us; reduce on 64ch x 6.5 M px: 1,024 blocks 429 us, 2,048 blocks 363 us.
+// Below ~128 MB per tensor the backward kernels are dominated by that per-block work (the atomics of the reduce kernel
+// serialise per address: 2,048 blocks / 8 replicas = 256 deep): 512 blocks there (n-scale 64ch x 204,800 px reduce: 52 -> 26 us).
+Geo geometry(long pixels, int C, int ve, int kind /*0 fwd, 1 bwd reduce, 2 bwd apply*/) {
   Geo g;
   const int CG = C / ve;
   g.cgb = CG < NT ? CG : NT;
   g.rows = NT / g.cgb;
-  long want = (pixels + (long)ppt * g.rows - 1) / ((long)ppt * g.rows);
-  int gx = (int)(want > max_x ? max_x : (want < 1 ? 1 : want));
-  g.grid = dim3(gx, dy_cdiv(CG, g.cgb));
+  static const int env_tgt = getenv("DY_BN_BLOCKS") ? atoi(getenv("DY_BN_BLOCKS")) : 0;       // tuning aid
+  long target = (1L << 18) / (C > 0 ? C : 1);
+  target = target > 2048 ? 2048 : (target < 256 ? 256 : target);
+  if (kind != 0 && pixels * C * (ve == 8 ? 2 : 4) <= (128L << 20) && target > 512) target = 512;
+  if (env_tgt > 0) target = env_tgt;
+  const int gy = dy_cdiv(CG, g.cgb);
+  long gx = (target + gy - 1) / gy;
+  const long cap = (pixels + 4L * g.rows - 1) / (4L * g.rows);          // at least 4 pixels per thread
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  g.grid = dim3((unsigned)gx, gy);
   return g;
 }
 
@@ -346,7 +361,7 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   if (residual) if (int e = check_view("dy_bn_act_fwd(res)", residual, res_ld, C, dtype)) return e;
   if (pixels <= 0) return 0;
   const int ve = dtype == DY_F32 ? 4 : 8;
-  const Geo g = geometry(pixels, C, ve, 4, 8192);
+  const Geo g = geometry(pixels, C, ve, 0);
   const size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
@@ -367,7 +382,7 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_reduce: null stats");
   if (pixels <= 0) return 0;
   const int ve = dtype == DY_F32 ? 4 : 8;
-  const Geo g = geometry(pixels, C, ve, 8, 1024);
+  const Geo g = geometry(pixels, C, ve, 1);
   size_t shm = 6 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
@@ -390,7 +405,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   DY_CHECK(sums && (!has_bn || (mean && invstd)), "dy_bn_act_bwd_apply: null stats");
   // pixels == 0: only the parameter gradients (dgamma / dbeta) are written
   const int ve = dtype == DY_F32 ? 4 : 8;
-  const Geo g = geometry(pixels > 0 ? pixels : 1, C, ve, 4, 8192);
+  const Geo g = geometry(pixels > 0 ? pixels : 1, C, ve, 2);
   const size_t shm = 7 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
