@@ -111,6 +111,24 @@ extern "C" int dy_adamw_step(float* p, const float* g, float* exp_avg, float* ex
   return 0;
 }
 
+namespace {
+__global__ void grad_accumulate_kernel(float* __restrict__ acc, const float* __restrict__ g, long n) {
+  const long n4 = n >> 2;
+  f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) a4[i] = a4[i] + g4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc[(n4 << 2) + threadIdx.x] += g[(n4 << 2) + threadIdx.x];
+}
+}  // namespace
+
+extern "C" int dy_grad_accumulate(float* acc, const float* g, int64_t n, void* stream) {
+  DY_CHECK(acc && g && n >= 0 && ((uintptr_t)acc % 16 == 0) && ((uintptr_t)g % 16 == 0), "dy_grad_accumulate: bad args");
+  if (n == 0) return 0;
+  grad_accumulate_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(acc, g, n);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream) {
   DY_CHECK(ema && src && n >= 0, "dy_ema_lerp: bad args");
   if (n == 0) return 0;

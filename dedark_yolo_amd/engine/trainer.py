@@ -201,7 +201,12 @@ class DetectionTrainer:
         if name == "AdamW":
             self.flat.m2 = torch.zeros_like(self.flat.m)
         self.mse_acc = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self.accumulate = 1
+        # trainer.py:248-249: accumulate gradients up to the nominal batch size nbs, scale weight_decay accordingly
+        nbs, bs = float(getattr(a, "nbs", 64)), max(int(getattr(a, "batch", 64)), 1)
+        self.accumulate = max(round(nbs / bs), 1)
+        self.weight_decay = a.weight_decay * bs * self.accumulate / nbs
+        self.last_opt_step = -1
+        self.acc_count = 0            # backward passes accumulated in flat.g_acc since the last optimizer step
         return self
 
     # ---------------------------------------------------------------- batch
@@ -242,24 +247,40 @@ class DetectionTrainer:
         """clip_grad_norm_(10.0) + optimizer.step() + zero_grad() + ema.update() (trainer.py:459-467) in 2 kernels."""
         f = self.flat
         st = stream()
+        g = f.g
+        if self.acc_count > 0:                  # gradients of the earlier backward passes wait in g_acc
+            call("dy_grad_accumulate", ptr(f.g_acc), ptr(f.g), f.n, st)
+            g = f.g_acc
         f.sumsq.zero_()
-        call("dy_sumsq", ptr(f.g), f.n, ptr(f.sumsq), st)
+        call("dy_sumsq", ptr(g), f.n, ptr(f.sumsq), st)
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000))                       # torch_utils.py:357
-        wd = self.args.weight_decay
+        wd = self.weight_decay
         if self.opt_name == "AdamW":
-            call("dy_adamw_step", ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.m2), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0,
+            call("dy_adamw_step", ptr(f.p), ptr(g), ptr(f.m), ptr(f.m2), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0,
                  mom, 0.999, 1e-8, self.updates, d, ptr(f.sumsq), 10.0, 1.0, f.n, st)
         else:
-            call("dy_sgd_step", ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0, mom, 1, d,
+            call("dy_sgd_step", ptr(f.p), ptr(g), ptr(f.m), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0, mom, 1, d,
                  ptr(f.sumsq), 10.0, 1.0, f.n, st)
         if f.buf_ema is not None and f.buf_flat.numel():
             call("dy_ema_lerp", ptr(f.buf_ema), ptr(f.buf_flat), d, f.buf_flat.numel(), st)
+        if self.acc_count > 0:
+            f.g_acc.zero_()
+            self.acc_count = 0
         ops.bump_weights_epoch()
         self.pack_plan.repack(self.model)
 
-    def train_step(self, batch, lr=None, mom=None):
-        """preprocess + forward + loss + backward (+ bucketed all-reduce) + optimizer/EMA. Returns (loss, loss_items)."""
+    def accumulate_gradients(self):
+        """Keep this backward pass's gradients for a later optimizer step (the conv kernels overwrite flat.g)."""
+        f = self.flat
+        if getattr(f, "g_acc", None) is None:
+            f.g_acc = torch.zeros_like(f.g)
+        call("dy_grad_accumulate", ptr(f.g_acc), ptr(f.g), f.n, stream())
+        self.acc_count += 1
+
+    def train_step(self, batch, lr=None, mom=None, step_optimizer=True):
+        """preprocess + forward + loss + backward (+ bucketed all-reduce) + optimizer/EMA. Returns (loss, loss_items).
+        step_optimizer=False only accumulates the gradients (trainer.py:340-342)."""
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
         loss.backward()
@@ -267,7 +288,10 @@ class DetectionTrainer:
             self.buckets.finish()
         if lr is None:
             lr, mom = [self.lr0] * 3, self.momentum
-        self.optimizer_step(lr, mom)
+        if step_optimizer:
+            self.optimizer_step(lr, mom)
+        else:
+            self.accumulate_gradients()
         self.step_count += 1
         return loss.detach(), items
 
@@ -276,10 +300,17 @@ class DetectionTrainer:
         nb = len(loader)
         nw = max(round(self.args.warmup_epochs * nb), 100) if self.args.warmup_epochs > 0 else -1
         history = []
+        nbs, bs = float(getattr(self.args, "nbs", 64)), max(int(getattr(self.args, "batch", 64)), 1)
         for epoch in range(epochs):
             for i, batch in enumerate(loader):
                 ni = i + nb * epoch
                 lr, mom = self.lr_factors(ni, nw, epoch, epochs)
-                loss, items = self.train_step(batch, lr, mom)
+                if ni <= nw:                                   # trainer.py:320-322: accumulate ramps from 1 to nbs / batch
+                    xi = ni / max(nw, 1)
+                    self.accumulate = max(1, round(1 + xi * (nbs / bs - 1)))
+                step = ni - self.last_opt_step >= self.accumulate        # trainer.py:340-342
+                loss, items = self.train_step(batch, lr, mom, step_optimizer=step)
+                if step:
+                    self.last_opt_step = ni
             history.append([float(v) for v in items])
         return history

@@ -251,6 +251,8 @@ int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, f
                   float ema_decay, const double* sumsq, float max_norm, float grad_scale, int64_t n, void* stream);
 /* ema = decay*ema + (1-decay)*src (EMA of the BatchNorm running buffers) */
 int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream);
+/* acc += g: gradient accumulation over `accumulate` batches (nbs / batch, U/engine/trainer.py:248,340-342) */
+int dy_grad_accumulate(float* acc, const float* g, int64_t n, void* stream);
 int dy_frontend_init(void); /* uploads the gaussian taps (call once per process, outside graph capture) */
 
 #ifdef __cplusplus

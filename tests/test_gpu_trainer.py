@@ -1,0 +1,133 @@
+"""GPU parity tests of the caller contract around the network: preprocess_batch against the oracle,
+and the fused clip + SGD(nesterov)/AdamW + EMA kernels (plus gradient accumulation) against torch.optim on the same
+gradients -- the reference's optimizer_step is clip_grad_norm_(10.0) -> optimizer.step() -> ema.update()
+(ultralytics/engine/trainer.py:459-467, build_optimizer :611-665, ModelEMA torch_utils.py:344-377)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import load_yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_trainer(optimizer, batch=64, **over):
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd.engine.trainer import DetectionTrainer, get_cfg
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    dy.set_compute_dtype(torch.float32)
+    cfgd = load_yaml("yolov8-lowlight.yaml")
+    cfgd["scales"]["t"] = [0.33, 0.125, 1024]
+    cfgd["scale"] = "t"
+    torch.manual_seed(3)
+    cfg = get_cfg(dict(model="tiny", dtype="fp32", optimizer=optimizer, batch=batch, lowlight_FLAG=True, dedark_FLAG=True, **over))
+    tr = DetectionTrainer(cfg)
+    tr.setup(DetectionModel(cfgd, nc=20))
+    return tr
+
+
+@pytest.mark.parametrize("low,ded", [(True, True), (True, False), (False, False)])
+def test_preprocess_batch_vs_oracle(low, ded):
+    from oracle import loss as oloss
+    tr = _tiny_trainer("SGD")
+    tr.args.lowlight_FLAG, tr.args.dedark_FLAG, tr.args.dark_param = low, ded, 7.3
+    g = np.random.default_rng(0)
+    img = torch.from_numpy(g.integers(0, 256, (3, 3, 40, 56), dtype=np.uint8))       # 20,160 pixels: vector body + scalar tail
+    out = tr.preprocess_batch(dict(img=img.clone()))
+    w_img, w_clean, w_rec = oloss.preprocess_batch(img, 7.3, low, ded)
+    assert float((out["img"].cpu() - w_img).abs().max()) <= 1e-6
+    assert float((out["clean_img"].cpu() - w_clean).abs().max()) <= 1e-6
+    assert abs(float(out["recovery_loss_batch"]) - float(w_rec)) <= 1e-6 * max(1.0, float(w_rec))
+
+
+def _reference_optimizer(tr, name, lr0, momentum, wd):
+    flat = tr.flat
+    refs, groups = [], {0: [], 1: [], 2: []}
+    for p, off, n, gid in flat.slots:
+        q = flat.p[off:off + n].detach().clone().view(p.shape).requires_grad_(True)
+        refs.append((q, off, n))
+        groups[gid].append(q)
+    pg = [dict(params=groups[2], weight_decay=0.0), dict(params=groups[0], weight_decay=wd), dict(params=groups[1], weight_decay=0.0)]
+    if name == "SGD":
+        opt = torch.optim.SGD(pg, lr=lr0, momentum=momentum, nesterov=True)
+    else:
+        opt = torch.optim.AdamW(pg, lr=lr0, betas=(momentum, 0.999))
+    return refs, opt
+
+
+@pytest.mark.parametrize("name", ["SGD", "AdamW"])
+def test_fused_optimizer_clip_ema_vs_torch(name):
+    tr = _tiny_trainer(name)
+    flat = tr.flat
+    assert tr.accumulate == 1 and abs(tr.weight_decay - tr.args.weight_decay) < 1e-12
+    refs, opt = _reference_optimizer(tr, name, tr.lr0, tr.momentum, tr.weight_decay)
+    ema = flat.p.detach().clone()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for step in range(1, 5):
+        scale = [0.02, 3.0, 0.5, 40.0][step - 1]                    # steps 2 and 4 exceed max_norm = 10 -> clipping is active
+        g = torch.randn(flat.n, generator=gen, device="cuda") * scale / math.sqrt(flat.n) * 10
+        flat.g.copy_(g)
+        lr = [tr.lr0 * 0.7, tr.lr0 * 0.9, tr.lr0 * 1.3] if step % 2 else [tr.lr0] * 3     # per-group lr (warm-up uses it)
+        mom = 0.85 if step == 1 else tr.momentum
+        tr.optimizer_step(lr, mom)
+        # --- torch reference on the same gradient
+        for q, off, n in refs:
+            q.grad = g[off:off + n].view(q.shape).clone()
+        torch.nn.utils.clip_grad_norm_([q for q, _, _ in refs], max_norm=10.0)
+        for grp, l in zip(opt.param_groups, (lr[2], lr[0], lr[1])):                        # torch group order: bias, decayed, norm
+            grp["lr"] = l
+            if name == "SGD":
+                grp["momentum"] = mom
+            else:
+                grp["betas"] = (mom, 0.999)
+        opt.step()
+        d = 0.9999 * (1 - math.exp(-step / 2000))
+        for q, off, n in refs:
+            ema[off:off + n].mul_(d).add_((1 - d) * q.detach().reshape(-1))
+        torch.cuda.synchronize()
+        for q, off, n in refs:
+            got, want = flat.p[off:off + n], q.detach().reshape(-1)
+            assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (name, step)
+            assert float((flat.ema[off:off + n] - ema[off:off + n]).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_gradient_accumulation_and_weight_decay_scaling():
+    """batch 16 with nbs 64: accumulate = 4 and weight_decay * 16 * 4 / 64 (trainer.py:248-249); the optimizer sees the SUM of
+    the accumulated gradients (the reference calls backward() repeatedly before optimizer.step())."""
+    tr = _tiny_trainer("SGD", batch=16)
+    assert tr.accumulate == 4 and abs(tr.weight_decay - tr.args.weight_decay * 16 * 4 / 64) < 1e-12
+    tr2 = _tiny_trainer("SGD", batch=24)                                # round(64 / 24) = 3 -> wd * 24 * 3 / 64
+    assert tr2.accumulate == 3 and abs(tr2.weight_decay - tr2.args.weight_decay * 72 / 64) < 1e-12
+    flat = tr.flat
+    refs, opt = _reference_optimizer(tr, "SGD", tr.lr0, tr.momentum, tr.weight_decay)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    gs = [torch.randn(flat.n, generator=gen, device="cuda") * 0.01 for _ in range(3)]
+    for g in gs[:2]:
+        flat.g.copy_(g)
+        tr.accumulate_gradients()
+    flat.g.copy_(gs[2])
+    tr.optimizer_step([tr.lr0] * 3, tr.momentum)
+    total = gs[0] + gs[1] + gs[2]
+    for q, off, n in refs:
+        q.grad = total[off:off + n].view(q.shape).clone()
+    torch.nn.utils.clip_grad_norm_([q for q, _, _ in refs], max_norm=10.0)
+    opt.step()
+    torch.cuda.synchronize()
+    for q, off, n in refs:
+        want = q.detach().reshape(-1)
+        assert float((flat.p[off:off + n] - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    assert tr.acc_count == 0 and float(flat.g_acc.abs().max()) == 0.0
+
+
+def test_train_loop_steps_optimizer_every_accumulate_batches():
+    """train(): with batch 32 / nbs 64 and no warm-up the optimizer runs on every second batch (trainer.py:340-342)."""
+    import bench
+    tr = _tiny_trainer("SGD", batch=32, warmup_epochs=0.0, epochs=1, imgsz=64)
+    batches = [bench.synth_batch(40 + i, 2, 64, 20, "cuda") for i in range(4)]
+    for b in batches:
+        b.pop("gamma"), b.pop("n_max")
+    before = tr.updates
+    hist = tr.train(batches, epochs=1)
+    assert tr.updates - before == 2 and len(hist) == 1 and all(np.isfinite(hist[0]))
