@@ -63,8 +63,8 @@ _SIGS = {
     "dy_resize_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "dy_filter_params_fwd": [vp, i32, vp, i32, vp],
     "dy_filter_params_bwd": [vp, i32, vp, vp, i32, vp],
-    "dy_filters_pointwise_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "dy_filters_pointwise_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dy_filters_pointwise_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dy_filters_pointwise_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "dy_usm_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "dy_usm_bwd": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "dy_loss_prepare_targets": [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],

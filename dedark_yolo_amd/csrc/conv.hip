@@ -26,6 +26,14 @@ bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
 int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
                        long scratch_elems, float* g_oihw, void* stream);
+// whole-input windows = fully connected layers (dense.hip)
+bool dy_dense_fwd_eligible(const dy_conv_desc* d);
+int dy_dense_fwd_launch(const dy_conv_desc* d, void* stream);
+bool dy_dense_dgrad_eligible(const dy_conv_desc* d);
+int dy_dense_dgrad_launch(const dy_conv_desc* d, void* stream);
+bool dy_dense_wgrad_eligible(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int pad, int dil);
+int dy_dense_wgrad_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout, int Cin,
+                          float* g_oihw, int dtype, void* stream);
 // direct stem kernels (conv_small.hip)
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
 int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream);
@@ -683,6 +691,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   const int ho = (d->Hs + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int wo = (d->Ws + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
+  if (dy_dense_fwd_eligible(d)) return dy_dense_fwd_launch(d, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
@@ -697,6 +706,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   DY_CHECK(ho == d->Hs && wo == d->Ws, "dy_conv2d_dgrad: dz %dx%d does not match conv output %dx%d", d->Hs, d->Ws, ho, wo);
   DY_CHECK(d->stats == nullptr, "dy_conv2d_dgrad: stats unsupported");
   DY_CHECK(d->KHf == 0 && d->dst_row_stride == 0, "dy_conv2d_dgrad: tap subsets / strided destinations are forward-only");
+  if (dy_dense_dgrad_eligible(d)) return dy_dense_dgrad_launch(d, stream);
   if (dy_conv_small_dgrad_eligible(d)) return dy_conv_small_dgrad_launch(d, stream);
   DY_CHECK(d->dst_planar == nullptr, "dy_conv2d_dgrad: dst_planar is only supported by the direct stem kernel (bf16, 3x3 s2 p1, Cd == 8)");
   static const bool no_parity = getenv("DY_NO_PARITY_DGRAD") != nullptr;
@@ -806,6 +816,8 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   DY_CHECK(((uintptr_t)x) % 16 == 0 && ((uintptr_t)dz) % 16 == 0, "dy_conv2d_wgrad: pointer not 16-byte aligned");
   const int ho = (Hi + 2 * pad - dil * (KH - 1) - 1) / stride + 1, wo = (Wi + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   DY_CHECK(ho == Ho && wo == Wo, "dy_conv2d_wgrad: dz %dx%d does not match conv output %dx%d", Ho, Wo, ho, wo);
+  if (dy_dense_wgrad_eligible(Hi, Wi, Ho, Wo, KH, KW, pad, dil))
+    return dy_dense_wgrad_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout, Cin, g_oihw, dtype, stream);
   if (dy_wgrad_v2_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, x_ld, dz_ld))
     return dy_wgrad_v2_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
                               scratch_elems, g_oihw, stream);

@@ -136,26 +136,36 @@ constexpr float LN2 = 0.69314718055994530942f;
 
 struct Px { float s1, s2, base, L, s3, rtx, txr; };
 
+// FAST: hardware transcendentals (throughput / bf16 mode); otherwise libm (f32 parity mode: bit-comparable with torch.pow)
+template <bool FAST>
 __device__ inline Px chain_px(float x, float A, float I, const FParams& p, int c) {
   Px r;
   r.txr = 1.f - p.omega * I;
-  r.rtx = __builtin_amdgcn_rcpf(fmaxf(r.txr, 0.01f));
-  r.s1 = (x - A) * r.rtx + A;
+  const float tx = fmaxf(r.txr, 0.01f);
+  r.rtx = FAST ? __builtin_amdgcn_rcpf(tx) : 1.f / tx;
+  r.s1 = FAST ? (x - A) * r.rtx + A : (x - A) / tx + A;
   r.s2 = r.s1 * p.s[c];
   r.base = fmaxf(r.s2, 1e-4f);
-  r.L = __builtin_amdgcn_logf(r.base);           // v_log_f32 = log2
-  r.s3 = __builtin_amdgcn_exp2f(p.gamma * r.L);  // v_exp_f32 = 2^x
+  if (FAST) {
+    r.L = __builtin_amdgcn_logf(r.base);           // v_log_f32 = log2
+    r.s3 = __builtin_amdgcn_exp2f(p.gamma * r.L);  // v_exp_f32 = 2^x
+  } else {
+    r.L = log2f(r.base);
+    r.s3 = powf(r.base, p.gamma);
+  }
   return r;
 }
 
+template <bool FAST>
 __device__ inline float row_lum(const float* xr, const float* ir, float Ac, const FParams& p, int c, int lane, int W, float* lraw_out) {
   float v = 0.f;
-  if (lane < 3 && lane < W) v = chain_px(xr[lane], Ac, ir ? ir[lane] : 0.5f, p, c).s3;
+  if (lane < 3 && lane < W) v = chain_px<FAST>(xr[lane], Ac, ir ? ir[lane] : 0.5f, p, c).s3;
   const float lraw = 0.27f * __shfl(v, 0, 64) + 0.67f * __shfl(v, 1, 64) + 0.06f * __shfl(v, 2, 64);
   *lraw_out = lraw;
   return fminf(fmaxf(lraw, 0.f), 1.f);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params,
                                                              const float* __restrict__ A, const float* __restrict__ IcA,
                                                              float* __restrict__ s4, int B, int H, int W) {
@@ -168,26 +178,28 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restr
   const float* xr = x + row * W;
   const float* ir = IcA ? IcA + ((long)b * H + h) * W : nullptr;
   float lraw;
-  const float lum = row_lum(xr, ir, Ac, p, c, lane, W, &lraw);
+  const float lum = row_lum<FAST>(xr, ir, Ac, p, c, lane, W, &lraw);
   // lerp(img, img/(lum+1e-6)*cl, alpha) (util_filters.py:316-317) = img * K with a per-row K
   const float cl = -cosf(3.14159265358979323846f * lum) * 0.5f + 0.5f;
   const float K = (1.f - p.alpha) + p.alpha * (cl / (lum + 1e-6f));
   float* o = s4 + row * W;
-  for (int w = lane; w < W; w += 64) o[w] = chain_px(xr[w], Ac, ir ? ir[w] : 0.5f, p, c).s3 * K;
+  for (int w = lane; w < W; w += 64) o[w] = chain_px<FAST>(xr[w], Ac, ir ? ir[w] : 0.5f, p, c).s3 * K;
 }
 
 struct PwAcc { float gamma, wb, om; };
 
 // backward of the chain for one pixel given d(loss)/d(s3); returns d(loss)/dx and accumulates the parameter gradients
+template <bool FAST>
 __device__ inline float chain_bwd_px(const Px& q, float x, float A, float I, float d3, const FParams& p, int c, PwAcc& a) {
   a.gamma += d3 * q.s3 * (q.L * LN2);
-  const float d2 = (q.s2 >= 1e-4f) ? d3 * p.gamma * q.s3 * __builtin_amdgcn_rcpf(q.base) : 0.f;
+  const float d2 = (q.s2 >= 1e-4f) ? d3 * p.gamma * (FAST ? q.s3 * __builtin_amdgcn_rcpf(q.base) : q.s3 / q.base) : 0.f;
   a.wb += d2 * q.s1;
   const float d1 = d2 * p.s[c];
   if (q.txr >= 0.01f) a.om += d1 * (x - A) * I * q.rtx * q.rtx;
   return d1 * q.rtx;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ params,
                                                              const float* __restrict__ A, const float* __restrict__ IcA,
                                                              const float* __restrict__ ds4, float* __restrict__ dx,
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
     const float* gr = ds4 + row * W;
     float* dxr = dx ? dx + row * W : nullptr;
     float lraw;
-    const float lum = row_lum(xr, ir, Ac, p, c, lane, W, &lraw);
+    const float lum = row_lum<FAST>(xr, ir, Ac, p, c, lane, W, &lraw);
     const float PI = 3.14159265358979323846f;
     const float cl = -cosf(PI * lum) * 0.5f + 0.5f;
     const float q = cl / (lum + 1e-6f);
@@ -220,9 +232,9 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
     float dK = 0.f;
     for (int w = lane; w < W; w += 64) {
       const float I = ir ? ir[w] : 0.5f, xv = xr[w], g4 = gr[w];
-      const Px px = chain_px(xv, Ac, I, p, c);
+      const Px px = chain_px<FAST>(xv, Ac, I, p, c);
       dK += g4 * px.s3;
-      const float g = chain_bwd_px(px, xv, Ac, I, g4 * K, p, c, acc);
+      const float g = chain_bwd_px<FAST>(px, xv, Ac, I, g4 * K, p, c, acc);
       if (dxr) dxr[w] = accumulate ? dxr[w] + g : g;
     }
     dK = wave_sum(dK);
@@ -236,8 +248,8 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
     if (lane < 3 && lane < W) {
       const float coef = lane == 0 ? 0.27f : (lane == 1 ? 0.67f : 0.06f);
       const float I = ir ? ir[lane] : 0.5f, xv = xr[lane];
-      const Px px = chain_px(xv, Ac, I, p, c);
-      const float g = chain_bwd_px(px, xv, Ac, I, coef * dlum, p, c, acc);
+      const Px px = chain_px<FAST>(xv, Ac, I, p, c);
+      const float g = chain_bwd_px<FAST>(px, xv, Ac, I, coef * dlum, p, c, acc);
       if (dxr) dxr[lane] += g;                                        // same lane wrote dxr[lane] in the loop above
     }
     t_om = wave_sum(acc.om);
@@ -305,18 +317,22 @@ extern "C" int dy_filter_params_bwd(const float* feat, int feat_ld, const float*
 }
 
 extern "C" int dy_filters_pointwise_fwd(const float* x, const float* params, const float* A, const float* IcA, float* s4, int B,
-                                        int H, int W, void* stream) {
+                                        int H, int W, int fast_math, void* stream) {
   DY_CHECK(x && params && s4 && B > 0 && H > 0 && W >= 3, "dy_filters_pointwise_fwd: bad args (W must be >= 3)");
-  pointwise_fwd_kernel<<<dy_cdiv((long)B * 3 * H, PW_ROWS), 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, s4, B, H, W);
+  const unsigned grid = dy_cdiv((long)B * 3 * H, PW_ROWS);
+  if (fast_math) pointwise_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, s4, B, H, W);
+  else pointwise_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, s4, B, H, W);
   DY_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int dy_filters_pointwise_bwd(const float* x, const float* params, const float* A, const float* IcA,
                                         const float* ds4, float* dx, float* dparams, int B, int H, int W, int accumulate,
-                                        void* stream) {
+                                        int fast_math, void* stream) {
   DY_CHECK(x && params && ds4 && dparams && B > 0 && H > 0 && W >= 3, "dy_filters_pointwise_bwd: bad args");
-  pointwise_bwd_kernel<<<dy_cdiv((long)B * 3 * H, PW_ROWS), 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, ds4, dx, dparams, B, H, W, accumulate);
+  const unsigned grid = dy_cdiv((long)B * 3 * H, PW_ROWS);
+  if (fast_math) pointwise_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, ds4, dx, dparams, B, H, W, accumulate);
+  else pointwise_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, params, A, IcA, ds4, dx, dparams, B, H, W, accumulate);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -570,7 +570,7 @@ class lowlight_recovery(DyModule):
         params = torch.empty((B, 8), dtype=f32, device=dev)
         call("dy_filter_params_fwd", ptr(feat), ld_of(feat), ptr(params), B, st)
         s4 = torch.empty((B, 3, H, W), dtype=f32, device=dev)
-        call("dy_filters_pointwise_fwd", ptr(x), ptr(params), ptr(A), ptr(I), ptr(s4), B, H, W, st)
+        call("dy_filters_pointwise_fwd", ptr(x), ptr(params), ptr(A), ptr(I), ptr(s4), B, H, W, int(ops.get_compute_dtype() != torch.float32), st)
         cd = ops.get_compute_dtype()
         out8 = torch.empty((B, H, W, 8), dtype=cd, device=dev).permute(0, 3, 1, 2)
         hp = torch.empty((B, 3, H, W), dtype=f32, device=dev) if tape is not None else None
@@ -595,7 +595,8 @@ class lowlight_recovery(DyModule):
         call("dy_usm_bwd", None, ptr(dout), dld, ptr(hp), ptr(params), ptr(ds4), ptr(dparams), B, H, W,
              ops.dt_id(dout.dtype), st)
         dx = torch.empty((B, 3, H, W), dtype=f32, device=dev) if need_dx else None
-        call("dy_filters_pointwise_bwd", ptr(x), ptr(params), ptr(s["A"]), ptr(s["I"]), ptr(ds4), ptr(dx), ptr(dparams), B, H, W, 0, st)
+        call("dy_filters_pointwise_bwd", ptr(x), ptr(params), ptr(s["A"]), ptr(s["I"]), ptr(ds4), ptr(dx), ptr(dparams), B, H, W, 0,
+             int(ops.get_compute_dtype() != torch.float32), st)
         fl = ld_of(feat)
         dfeat = torch.empty((B, 1, 1, fl), dtype=f32, device=dev).permute(0, 3, 1, 2)
         call("dy_filter_params_bwd", ptr(feat), fl, ptr(dparams), ptr(dfeat), B, st)

@@ -158,9 +158,10 @@ int dy_resize_bwd(const float* dy_nhwc, int dy_ld, int B, int H, int W, int Ho, 
 int dy_filter_params_fwd(const float* feat, int feat_ld, float* params, int B, void* stream);
 int dy_filter_params_bwd(const float* feat, int feat_ld, const float* dparams, float* dfeat, int B, void* stream);
 /* DeDark -> WB -> Gamma -> Contrast pointwise chain (filtersB.py:190-303) x -> s4 ; A [B,3] or NULL (0.8);
- * IcA [B,H,W] or NULL (0.5) */
+ * IcA [B,H,W] or NULL (0.5).  fast_math = 0: libm powf / division (f32 parity mode, comparable with torch.pow to ~1 ulp);
+ * fast_math = 1: v_log_f32 / v_exp_f32 / v_rcp_f32 (~2e-6 relative; the throughput mode, 10x faster backward) */
 int dy_filters_pointwise_fwd(const float* x, const float* params, const float* A, const float* IcA, float* s4, int B,
-                             int H, int W, void* stream);
+                             int H, int W, int fast_math, void* stream);
 /* USM (filtersB.py:153-175) as a separable 25-tap gaussian with reflect halo: out = (s4 - blur)*lambda + s4.
  * Writes out NCHW f32 (optional), the NHWC8 copy in `dtype` for the stem conv (optional), and hp = s4 - blur (optional). */
 int dy_usm_fwd(const float* s4, const float* params, float* out_nchw, void* out_nhwc8, float* hp, int B, int H, int W,
@@ -173,7 +174,7 @@ int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc, int dout_ld, const
 /* pointwise backward: recomputes the chain from x, consumes ds4, writes dx (overwrite or +=; NULL = not needed) and
  * accumulates dparams[b, 0..5] */
 int dy_filters_pointwise_bwd(const float* x, const float* params, const float* A, const float* IcA, const float* ds4,
-                             float* dx, float* dparams, int B, int H, int W, int accumulate, void* stream);
+                             float* dx, float* dparams, int B, int H, int W, int accumulate, int fast_math, void* stream);
 
 /* ------------------------------------------------------------------------------------------ detection loss
  * v8DetectionLoss / RcoveryDetectionLoss (U/utils/loss.py:103-193,388-416), TaskAlignedAssigner (U/utils/tal.py),

@@ -30,7 +30,8 @@ def _case(dtype, B, Cin, Cout, H, W, k, s, p, d=1):
     from dedark_yolo_amd import ops
     torch.manual_seed(B * 1000 + Cin + Cout + H)
     x = torch.randn(B, Cin, H, W, device="cuda")
-    w = (torch.randn(Cout, Cin, k, k, device="cuda") * (1.0 / (Cin * k * k) ** 0.5)).requires_grad_(True)
+    kh, kw = k if isinstance(k, tuple) else (k, k)
+    w = (torch.randn(Cout, Cin, kh, kw, device="cuda") * (1.0 / (Cin * kh * kw) ** 0.5)).requires_grad_(True)
     bias = torch.randn(Cout, device="cuda").requires_grad_(True)
     xr = x.to(dtype).float().clone().requires_grad_(True)
     wq = w.detach().to(dtype).float().requires_grad_(True)
@@ -53,7 +54,9 @@ GENERIC = [(1, 8, 32, 4, 4, 1, 1, 0), (2, 24, 16, 9, 7, 1, 1, 0), (2, 16, 32, 12
            (1, 64, 128, 20, 20, 3, 1, 1), (1, 32, 8, 10, 9, 3, 1, 2, 2), (2, 256, 256, 8, 8, 3, 1, 1), (2, 8, 16, 33, 31, 5, 1, 2),
            (2, 16, 32, 13, 21, 3, 2, 1),      # stride-2 dgrad as 4 parity classes, odd sizes
            (2, 8, 16, 12, 14, 1, 2, 0),       # k1 s2: empty parity classes -> masked fallback
-           (1, 8, 16, 17, 16, 5, 2, 2)]       # k5 s2: unequal class pads -> masked fallback
+           (1, 8, 16, 17, 16, 5, 2, 2),       # k5 s2: unequal class pads -> masked fallback
+           (5, 32, 64, 8, 8, 8, 1, 0),        # whole-input window = fully connected layer (dense.hip)
+           (3, 16, 24, 4, 6, (4, 6), 1, 0)]   # ... non-square
 PIPELINED = [(2, 64, 128, 40, 40, 3, 1, 1), (3, 128, 64, 32, 32, 3, 2, 1), (2, 64, 128, 65, 63, 3, 2, 1),
              (2, 256, 192, 48, 48, 1, 1, 0), (1, 64, 64, 50, 47, 3, 1, 1), (2, 192, 320, 24, 24, 3, 1, 1),
              (3, 64, 128, 40, 40, 3, 1, 1), (8, 96, 80, 37, 41, 3, 1, 1), (16, 64, 128, 40, 40, 3, 2, 1),

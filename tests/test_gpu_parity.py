@@ -151,8 +151,11 @@ def test_ka1_filter_chain_on_gpu():
     p = params.cpu()[0]
     close(p[:7], torch.tensor([0.2072826, 1.2354821, 0.9091753, 0.9543331, 0.6414791, 0.6947827, 4.4039855]), 1e-5, 1e-6, "KA1 params")
     s4 = torch.empty_like(x)
-    call("dy_filters_pointwise_fwd", ptr(x), ptr(params), None, None, ptr(s4), 1, 16, 20, stream())
+    call("dy_filters_pointwise_fwd", ptr(x), ptr(params), None, None, ptr(s4), 1, 16, 20, 0, stream())
     close(s4.cpu(), g["s4"], 1e-5, 1e-5, "KA1 contrast stage")
+    s4_fast = torch.empty_like(x)                   # throughput-mode transcendentals (v_log/v_exp/v_rcp): ~2e-6 relative
+    call("dy_filters_pointwise_fwd", ptr(x), ptr(params), None, None, ptr(s4_fast), 1, 16, 20, 1, stream())
+    close(s4_fast.cpu(), g["s4"], 2e-5, 2e-5, "KA1 contrast stage, fast math")
     out = torch.empty_like(x)
     call("dy_usm_fwd", ptr(s4), ptr(params), ptr(out), None, None, 1, 16, 20, 0, stream())
     close(out.cpu(), g["s5"], 2e-5, 2e-5, "KA1 usm stage")
