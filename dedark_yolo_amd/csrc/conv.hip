@@ -773,9 +773,13 @@ int launch_wgrad(WgP p, float* scratch, long scratch_elems, float* g_oihw, int C
   p.tiles_k = dy_cdiv(p.Ktot, bn);
   const int tiles = tiles_c * p.tiles_k;
   p.tiles = tiles;
-  // enough splits to fill the chip (~4 blocks per CU), at least 4 steps of pixels per split, and the slabs must fit
-  long max_splits = (p.M + 4 * MK - 1) / (4 * MK);
-  long want = (1024 + tiles - 1) / tiles;
+  // enough splits to fill the chip (~8 blocks per CU: swept with tools/wgrad_sweep.py on the n-scale shapes, 2048 blocks beat
+  // 1024 by 7 % and 256 lose 55 %), at least 4 steps of pixels per split, and the slabs must fit
+  static const int env_blocks = getenv("DY_WGRAD_BLOCKS") ? atoi(getenv("DY_WGRAD_BLOCKS")) : 0;     // tuning aids
+  static const int env_steps = getenv("DY_WGRAD_STEPS") ? atoi(getenv("DY_WGRAD_STEPS")) : 0;
+  const int min_steps = env_steps > 0 ? env_steps : 4;
+  long max_splits = (p.M + (long)min_steps * MK - 1) / ((long)min_steps * MK);
+  long want = ((env_blocks > 0 ? env_blocks : 2048) + tiles - 1) / tiles;
   long splits = want < max_splits ? want : max_splits;
   const long fit = scratch_elems / ((long)tiles * bm * bn);
   DY_CHECK(fit >= 1, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems, (long)tiles * bm * bn);
