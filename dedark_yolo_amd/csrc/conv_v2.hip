@@ -72,7 +72,9 @@ __device__ inline int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-template <int BN, int MODE>
+// SMALLC: Cs is not a multiple of 64 (the n-scale layers, 8..48 channels): a 64-wide K-step then spans several taps, so every
+// lane derives (tap, channel) of ITS 16-byte chunk; K = KH*KW*Cs is padded to the step with zero-page loads.
+template <int BN, int MODE, bool SMALLC>
 __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   constexpr int WN = 2, WM = 4;
   constexpr int TM = BM / WM / 32;          // 2
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
     int img = (int)(mm / HWd);
     int rem = (int)(mm - (long)img * HWd);
     int oh = rem / p.Wd, ow = rem - oh * p.Wd;
-    a_base[j] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + chunk * 8) * 2;
+    a_base[j] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + (SMALLC ? 0 : chunk * 8)) * 2;
     if (MODE == 0) {
       a_h[j] = oh * p.stride - p.pad;
       a_w[j] = ow * p.stride - p.pad;
@@ -120,18 +122,29 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   for (int j = 0; j < B_LD; ++j) {
     int n = n0 + 8 * (wave + 8 * j) + lrow;
     b_ok[j] = n < p.Cd;
-    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.w_row + chunk * 8) * 2;
+    b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.w_row + (SMALLC ? 0 : chunk * 8)) * 2;
   }
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   int kh = 0, kw = 0, ci = 0;              // tap / channel offset of the NEXT stage to issue
+  int kstep = 0;
 
   auto issue = [&](int buf) {
     char* stage = smem + buf * STAGE;
-    // tap geometry is uniform for the whole K-step (Cs % 64 == 0)
+    bool kvalid = true;
+    if (SMALLC) {                            // per-lane tap of this lane's chunk
+      const int kk = kstep * BK + chunk * 8;
+      kvalid = kk < p.Ktot;
+      const int tap = kvalid ? kk / p.Cs : 0;
+      ci = kvalid ? kk - tap * p.Cs : 0;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+      ++kstep;
+    }
+    // otherwise the tap geometry is uniform for the whole K-step (Cs % 64 == 0)
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int sh, sw;
-      bool ok = a_ok[j];
+      bool ok = a_ok[j] && kvalid;
       if (MODE == 0) {
         sh = a_h[j] + kh * p.dil;
         sw = a_w[j] + kw * p.dil;
@@ -154,13 +167,15 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
     const long wk = ((long)((p.kh0 + p.khs * kh) * p.KWf + p.kw0 + p.kws * kw) * p.Cs + ci) * 2;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const char* g = b_ok[j] ? b_ptr[j] + wk : zero;
+      const char* g = (b_ok[j] && kvalid) ? b_ptr[j] + wk : zero;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + BM * ROW + (wave + 8 * j) * 1024), 16, 0, 0);
     }
-    ci += BK;
-    if (ci >= p.Cs) {
-      ci = 0;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    if (!SMALLC) {
+      ci += BK;
+      if (ci >= p.Cs) {
+        ci = 0;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
     }
   };
 
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = p.Ktot / BK;
+  const int nsteps = (p.Ktot + BK - 1) / BK;
   const int fr = lane & 31, fh = lane >> 5;
   // fragment row byte offsets (swizzle key (row>>1)&7 is per row)
   int a_off[TM], a_key[TM], b_off[TN], b_key[TN];
@@ -274,12 +289,12 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   }
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, bool SMALLC>
 int launch(P& p, hipStream_t st) {
   constexpr int SHMEM = NSTAGE * (BM + BN) * ROW;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BN, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BN, MODE, SMALLC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) {
       dy_set_error("conv_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -289,7 +304,7 @@ int launch(P& p, hipStream_t st) {
   }
   p.tiles_n = dy_cdiv(p.Cd, BN);
   p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
-  conv_kernel<BN, MODE><<<p.nblk, NT, SHMEM, st>>>(p);
+  conv_kernel<BN, MODE, SMALLC><<<p.nblk, NT, SHMEM, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -305,7 +320,13 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d) {
   static const bool off = getenv("DY_NO_CONV_V2") != nullptr;
   if (off) return false;
   const long M = (long)d->N * d->Hd * d->Wd;
-  return d->dtype == DY_BF16 && d->Cs % 64 == 0 && d->Cd >= 64 && M >= 2048 && (d->src_ld * 2) % 16 == 0;
+  if (!(d->dtype == DY_BF16 && M >= 2048 && (d->src_ld * 2) % 16 == 0)) return false;
+  if (d->Cs % 64 == 0) return d->Cd >= 64;
+  // narrow SOURCE channels (per-lane tap decode, SMALLC).  Measured on the n-scale layers: a win only when the destination is
+  // at least one 64-wide tile (96->64 1x1: 50 -> 40 us, 32->64 3x3 s2: 61 -> 54 us); with Cd <= 32 the 256x64 tile is 50-75 %
+  // padding and its epilogue-bound blocks lose to the register-staged kernel (32->32 3x3: 31 -> 49 us).  DY_V2_SMALLC=1 forces it.
+  static const bool force = getenv("DY_V2_SMALLC") != nullptr;
+  return d->Cs % 8 == 0 && d->Cd % 8 == 0 && (d->Cd >= 64 || (force && d->Cd >= 8));
 }
 
 int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
@@ -329,6 +350,10 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   const bool wide = d->Cd > 64;
-  if (mode == 0) return wide ? v2::launch<128, 0>(p, st) : v2::launch<64, 0>(p, st);
-  return wide ? v2::launch<128, 1>(p, st) : v2::launch<64, 1>(p, st);
+  if (d->Cs % 64 != 0) {
+    if (mode == 0) return wide ? v2::launch<128, 0, true>(p, st) : v2::launch<64, 0, true>(p, st);
+    return wide ? v2::launch<128, 1, true>(p, st) : v2::launch<64, 1, true>(p, st);
+  }
+  if (mode == 0) return wide ? v2::launch<128, 0, false>(p, st) : v2::launch<64, 0, false>(p, st);
+  return wide ? v2::launch<128, 1, false>(p, st) : v2::launch<64, 1, false>(p, st);
 }
