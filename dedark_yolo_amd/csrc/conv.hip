@@ -13,6 +13,7 @@
 // weight panel stay L2-resident).
 #include <stdlib.h>
 #include "dy_common.h"
+#include "conv_epilogue.h"
 #include "../../include/dedark_yolo.h"
 
 // pipelined wide-channel bf16 kernel (conv_v2.hip)
@@ -263,33 +264,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
   T* dst = reinterpret_cast<T*>(p.dst);
-  int nn[TN];
-  bool nok[TN];
-  float sc[TN], sf[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    nn[j] = n0 + wn * (BN / WN) + j * 32 + cl;
-    nok[j] = nn[j] < p.Cd;
-    sc[j] = (nok[j] && p.scale) ? p.scale[nn[j]] : 1.f;
-    sf[j] = (nok[j] && p.shift) ? p.shift[nn[j]] : 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (m >= p.M) continue;
-      T* orow = dst + dst_offset(p, m);          // one pixel decode per row (strided destinations of the parity-split dgrad)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (nok[j]) {
-          float a = acc[i][j][r];
-          csum[j] += a;
-          csq[j] += a * a;
-          float v = dy_act(p.act, a * sc[j] + sf[j]);
-          T* o = orow + nn[j];
-          if (p.accumulate) v += DT<T>::ld(o);
-          if (!(p.ablate & 4)) DT<T>::st(o, v);
+  if constexpr (sizeof(T) == 2) {
+    // bf16: transposed LDS image + ds_read_b64_tr_b16 -> 16-byte stores (conv_epilogue.h); the per-lane 2-byte stores of the
+    // scalar path below wrote 64-byte row fragments and made the narrow n-scale layers store-bound
+    static_assert(dy_epi::image_bytes<BM, BN>() <= (BM + BN) * ROWB, "epilogue image must fit the staging buffers");
+    if (!(p.ablate & 4))
+      dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act,
+                                                 p.accumulate, reinterpret_cast<bf16_t*>(dst),
+                                                 [&](long m) { return dst_offset(p, m); }, csum, csq);
+  } else {
+    int nn[TN];
+    bool nok[TN];
+    float sc[TN], sf[TN];
+  #pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      nn[j] = n0 + wn * (BN / WN) + j * 32 + cl;
+      nok[j] = nn[j] < p.Cd;
+      sc[j] = (nok[j] && p.scale) ? p.scale[nn[j]] : 1.f;
+      sf[j] = (nok[j] && p.shift) ? p.shift[nn[j]] : 0.f;
+    }
+  #pragma unroll
+    for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m >= p.M) continue;
+        T* orow = dst + dst_offset(p, m);          // one pixel decode per row (strided destinations of the parity-split dgrad)
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (nok[j]) {
+            float a = acc[i][j][r];
+            csum[j] += a;
+            csq[j] += a * a;
+            float v = dy_act(p.act, a * sc[j] + sf[j]);
+            T* o = orow + nn[j];
+            if (p.accumulate) v += DT<T>::ld(o);
+            if (!(p.ablate & 4)) DT<T>::st(o, v);
+          }
         }
       }
     }

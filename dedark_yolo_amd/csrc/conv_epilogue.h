@@ -1,4 +1,4 @@
-// Shared epilogue of the pipelined bf16 conv kernels (conv_v2.hip, conv_v3.hip): f32 accumulators -> affine + activation ->
+// Shared epilogue of the bf16 conv kernels (conv.hip, conv_v2.hip, conv_v3.hip): f32 accumulators -> affine + activation ->
 // bf16 tile in HBM with 16-byte stores, plus the per-channel (sum, sum of squares) of the RAW accumulators for BatchNorm.
 //
 // The 32x32 MFMA leaves lane (col = lane&31, half hh = lane>>5) with rows (r&3) + 8*(r>>2) + 4*hh of ONE column: four
@@ -13,22 +13,24 @@
 
 namespace dy_epi {
 
-constexpr int PT = 520;      // bytes per imageT row (256 rows x 2 B + 8 B pad)
+template <int BM>
+constexpr int pitch() { return BM * 2 + 8; }      // bytes per imageT row (BM rows x 2 B + 8 B pad)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <int BN>
-constexpr int image_bytes() { return BN * PT; }
+template <int BM, int BN>
+constexpr int image_bytes() { return BN * pitch<BM>(); }
 
 __device__ inline uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 
-// BM must be 256 (PT), 8 waves as WM x WN = 4 x 2, wave tile 64 x (BN/2).  `off(m)` = element offset of output pixel m.
-template <int BN, int TM, int TN, typename OffFn>
+// Block tile BM x BN on WM x WN waves (wave tile 32*TM x 32*TN).  `off(m)` = element offset of output pixel m.
+template <int BM, int BN, int WM, int WN, int TM, int TN, typename OffFn>
 __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int wn, int lane, int wave, long m0, int n0, long M, int Cd,
                                   const float* scale, const float* shift, int act, int accumulate, bf16_t* dst, OffFn off,
                                   float (&csum)[TN], float (&csq)[TN]) {
-  constexpr int BM = 256, WN = 2;
+  constexpr int PT = pitch<BM>();
+  static_assert(BM / WM == 32 * TM && BN / WN == 32 * TN, "wave tiling");
   const int cl = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
@@ -42,7 +44,7 @@ __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int
     const float sf = (nok && shift) ? shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row0 = wm * (BM / 4) + i * 32 + 4 * hh;
+      const int row0 = wm * (BM / WM) + i * 32 + 4 * hh;
       const long mrem = M - (m0 + row0);           // rows with (r&3)+8*(r>>2) < mrem are real pixels
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
@@ -68,7 +70,7 @@ __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int
   // ---- store phase: unit = 16 pixels x 32 channels per wave instruction
   constexpr int UP = BM / 16, UC = BN / 32;
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int u = wave; u < UP * UC; u += 8) {
+  for (int u = wave; u < UP * UC; u += WM * WN) {
     const int pt = u / UC, ct = u - pt * UC;
     const int cb = ct * 32 + 8 * g;                // first channel of this lane's 8-channel vector
     const char* base = smem + (cb + tq) * PT + (pt * 16 + 4 * tp) * 2;

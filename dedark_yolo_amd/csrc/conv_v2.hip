@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
   if (!(p.ablate & 4))
-    dy_epi::store_tile<BN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
+    dy_epi::store_tile<BM, BN, 4, 2, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
                                    reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
   stamp(p.ablate, 6);
   stamp(p.ablate, 7);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
   if (!(p.ablate & 4))
-    dy_epi::store_tile<BN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
+    dy_epi::store_tile<BM, BN, 4, 2, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
                                    reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return m * p.dst_ld; }, csum, csq);
   stamp(p.ablate, 6);
   stamp(p.ablate, 7);
@@ -295,7 +295,7 @@ template <int BN>
 int shmem_bytes(const P& p) {
   const int nchunks = p.Cs / BK;
   int ring = (nchunks > 1 ? 2 : 1) * p.a_bytes + NB * BN * ROW;
-  int epi = dy_epi::image_bytes<BN>();
+  int epi = dy_epi::image_bytes<BM, BN>();
   return ring > epi ? ring : epi;
 }
 
