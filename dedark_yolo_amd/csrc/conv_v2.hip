@@ -4,9 +4,9 @@
 // MFMA pipe and HBM (ds_write staging pass, two barriers per K-step, address VALU).  This kernel removes that pass:
 //   * A (gathered activations) and B (packed weights) tiles go global -> LDS directly (global_load_lds, 16 B per lane, the
 //     per-lane SOURCE address does the implicit-GEMM gather; padding taps read a zero page), no VGPR staging, no ds_write;
-//   * 3-stage LDS ring, ONE raw s_barrier per K-step, counted s_waitcnt vmcnt(N) so the next stage stays in flight across
-//     the barrier (never drained to 0 inside the loop);
-//   * 256 x BN block tile on 8 waves (4 x 2), K-step 64 bf16 = 128-byte LDS rows, XOR swizzle (16-byte slot ^ (row>>1)&7)
+//   * NSTAGE-deep LDS ring, ONE raw s_barrier per K-step, counted s_waitcnt vmcnt(N) (with 3 stages the next stage stays in
+//     flight across the barrier); the shipped shapes use 2 stages so that TWO blocks are co-resident per CU (see the launcher);
+//   * BM x BN block tile on (BM/64) x 2 waves, K-step 64 bf16 = 128-byte LDS rows, XOR swizzle (16-byte slot ^ (row>>1)&7)
 //     applied on the source side (the DMA image is lane-linear) and on the ds_read_b128 side: conflict-free fragments;
 //   * v_mfma_f32_32x32x16_bf16, f32 accumulate; BatchNorm batch statistics from the accumulators (replicated f64 atomics).
 // Requirements (checked by the dispatcher): bf16, Cs % 64 == 0 (a K-step never straddles two taps), dense 16-byte aligned views.
@@ -17,7 +17,7 @@
 
 namespace v2 {
 
-constexpr int BM = 256, BK = 64, NT = 512, NSTAGE = 3;
+constexpr int BK = 64;
 constexpr int ROW = 128;                 // bytes per LDS row (64 bf16)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -74,9 +74,10 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 
 // SMALLC: Cs is not a multiple of 64 (the n-scale layers, 8..48 channels): a 64-wide K-step then spans several taps, so every
 // lane derives (tap, channel) of ITS 16-byte chunk; K = KH*KW*Cs is padded to the step with zero-page loads.
-template <int BN, int MODE, bool SMALLC>
-__global__ __launch_bounds__(NT) void conv_kernel(P p) {
-  constexpr int WN = 2, WM = 4;
+// BM x BN block tile on (BM/64) x 2 waves (wave tile 64 x BN/2); NSTAGE-deep LDS ring.
+template <int BM, int BN, int MODE, bool SMALLC, int NSTAGE>
+__global__ __launch_bounds__(BM * 2) void conv_kernel(P p) {
+  constexpr int WN = 2, WM = BM / 64, NW = WM * WN, NT = 64 * NW;
   constexpr int TM = BM / WM / 32;          // 2
   constexpr int TN = BN / WN / 32;          // 2 (BN=128) or 1 (BN=64)
   constexpr int A_LD = BM * 8 / NT;         // glds per thread for A per stage (4)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   const long HWd = (long)p.Hd * p.Wd;
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    long m = m0 + 8 * (wave + 8 * j) + lrow;
+    long m = m0 + 8 * (wave + NW * j) + lrow;
     a_ok[j] = m < p.M;
     long mm = a_ok[j] ? m : 0;
     int img = (int)(mm / HWd);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   bool b_ok[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    int n = n0 + 8 * (wave + 8 * j) + lrow;
+    int n = n0 + 8 * (wave + NW * j) + lrow;
     b_ok[j] = n < p.Cd;
     b_ptr[j] = p.w + ((long)(b_ok[j] ? n : 0) * p.w_row + (SMALLC ? 0 : chunk * 8)) * 2;
   }
@@ -162,13 +163,13 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
       }
       ok = ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws;
       const char* g = ok ? a_base[j] + (((long)sh * p.Ws + sw) * p.src_ld + ci) * 2 : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (wave + NW * j) * 1024), 16, 0, 0);
     }
     const long wk = ((long)((p.kh0 + p.khs * kh) * p.KWf + p.kw0 + p.kws * kw) * p.Cs + ci) * 2;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const char* g = (b_ok[j] && kvalid) ? b_ptr[j] + wk : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + BM * ROW + (wave + 8 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + BM * ROW + (wave + NW * j) * 1024), 16, 0, 0);
     }
     if (!SMALLC) {
       ci += BK;
@@ -206,15 +207,15 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
 
   stamp(p.ablate, 1);
   issue(0);
-  if (nsteps > 1) issue(1);
+  if (NSTAGE > 2 && nsteps > 1) issue(1);
   stamp(p.ablate, 2);
   for (int s = 0; s < nsteps; ++s) {
     if (s == 1) stamp(p.ablate, 3);
     if (s == 9) stamp(p.ablate, 4);
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+    if (NSTAGE > 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < nsteps && !(p.ablate & 1)) issue((s + 2) % NSTAGE);
+    if (s + NSTAGE - 1 < nsteps && !(p.ablate & 1)) issue((s + NSTAGE - 1) % NSTAGE);
     const char* stage = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
   if (!(p.ablate & 4))
-    dy_epi::store_tile<BM, BN, 4, 2, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
+    dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
                                    reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
   stamp(p.ablate, 6);
   stamp(p.ablate, 7);
@@ -289,12 +290,12 @@ __global__ __launch_bounds__(NT) void conv_kernel(P p) {
   }
 }
 
-template <int BN, int MODE, bool SMALLC>
+template <int BN, int MODE, bool SMALLC, int NSTAGE = 3, int BM = 256>
 int launch(P& p, hipStream_t st) {
   constexpr int SHMEM = NSTAGE * (BM + BN) * ROW;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BN, MODE, SMALLC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BM, BN, MODE, SMALLC, NSTAGE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) {
       dy_set_error("conv_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -304,7 +305,7 @@ int launch(P& p, hipStream_t st) {
   }
   p.tiles_n = dy_cdiv(p.Cd, BN);
   p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
-  conv_kernel<BN, MODE, SMALLC><<<p.nblk, NT, SHMEM, st>>>(p);
+  conv_kernel<BM, BN, MODE, SMALLC, NSTAGE><<<p.nblk, BM * 2, SHMEM, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -351,9 +352,16 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool wide = d->Cd > 64;
   if (d->Cs % 64 != 0) {
-    if (mode == 0) return wide ? v2::launch<128, 0, true>(p, st) : v2::launch<64, 0, true>(p, st);
-    return wide ? v2::launch<128, 1, true>(p, st) : v2::launch<64, 1, true>(p, st);
+    if (mode == 0) return wide ? v2::launch<128, 0, true, 2, 128>(p, st) : v2::launch<64, 0, true, 2, 256>(p, st);
+    return wide ? v2::launch<128, 1, true, 2, 128>(p, st) : v2::launch<64, 1, true, 2, 256>(p, st);
   }
-  if (mode == 0) return wide ? v2::launch<128, 0, false>(p, st) : v2::launch<64, 0, false>(p, st);
-  return wide ? v2::launch<128, 1, false>(p, st) : v2::launch<64, 1, false>(p, st);
+  // Tile shapes (swept with tools/conv_bench, DY_V2_EXP): two CO-RESIDENT blocks per CU beat one bigger block with a deeper
+  // ring -- their barriers and epilogue bursts interleave.  Wide outputs: 128x128 tile on 4 waves, 2 stages = 64 KB (2 blocks /
+  // CU; 256->256 3x3 254 -> 239 us, 1280->512 1x1 302 -> 286 us vs 256x128 x 3 stages).  Cd <= 64: 256x64 on 8 waves, 2 stages =
+  // 80 KB (64->64 3x3 at 160x160: 433 -> 333 us, also 20 % faster than the band kernel's 64-wide variant).
+  static const int exp_mode = getenv("DY_V2_EXP") ? atoi(getenv("DY_V2_EXP")) : 0;
+#define DY_V2_GO(BN_, NS_, BM_) (mode == 0 ? v2::launch<BN_, 0, false, NS_, BM_>(p, st) : v2::launch<BN_, 1, false, NS_, BM_>(p, st))
+  if (exp_mode == 1) return wide ? DY_V2_GO(128, 3, 256) : DY_V2_GO(64, 3, 256);        // the first version: one block per CU
+  return wide ? DY_V2_GO(128, 2, 128) : DY_V2_GO(64, 2, 256);
+#undef DY_V2_GO
 }
