@@ -12,8 +12,8 @@
 //   * fragments are read with ds_read_b64_tr_b16 (CDNA4 transposing LDS read: a 16-lane group fetches 4 pixels x 16 channels
 //     and each lane receives the 4 pixels of ITS channel), two reads = one 32x32x16 operand; the swizzle above is
 //     conflict-free for these reads;
-//   * 3-stage ring, one raw barrier per step, counted vmcnt (as conv_v2.hip); block tile 256 (k') x 128 (co), 8 waves (4 x 2),
-//     16 MFMA per wave and step;
+//   * LDS ring with one raw barrier per step (as conv_v2.hip); shipped shape: 128 (k') x 128 (co) block tile on 4 waves, 2 stages =
+//     64 KiB so that two blocks share a CU (the 256 x 128 x 3-stage single-block shape is DY_WG2_EXP=1); 16 MFMA per wave and step;
 //   * the pixel range is split over gridDim.y; partial tiles go to `scratch` and a second kernel adds them in a fixed order
 //     (deterministic) while scattering to the OIHW f32 master-gradient layout.
 #include <stdlib.h>
@@ -22,11 +22,8 @@
 
 namespace wg2 {
 
-constexpr int BP = 256, BQ = 128, BKP = 64, NT = 512, NSTAGE = 3;
+constexpr int BQ = 128, BKP = 64;
 constexpr int IMG = BKP * 256;                 // one [64][128ch] image: 16 KiB
-constexpr int STAGE = 3 * IMG;                 // two x images (256 k') + one dz image (128 co)
-constexpr int A_LD = 4, B_LD = 2;              // global_load_lds per lane and stage
-constexpr int SHMEM = NSTAGE * STAGE;          // 144 KiB
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -51,8 +48,15 @@ struct P {
   int pointwise;
 };
 
-__global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
-  constexpr int TM = 2, TN = 2;                  // 8 waves as 4 (k') x 2 (co), 64 x 64 outputs per wave
+// BP (k') x 128 (co) block tile on (BP/64) x 2 waves, 64 x 64 outputs per wave, NSTAGE-deep ring of (BP/128 + 1) images.
+template <int BP, int NSTAGE>
+__global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int NA = BP / 128;                   // x images per stage
+  constexpr int NW = BP / 32;                    // waves
+  constexpr int NROW = 16 / NW;                  // distinct tile rows per lane inside one image (4 rows per wave instruction)
+  constexpr int A_LD = NA * NROW, B_LD = NROW;   // global_load_lds per lane and stage
+  constexpr int STAGE = (NA + 1) * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -68,12 +72,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
   int a_kh[A_LD], a_kw[A_LD];
   long a_coff[A_LD];                 // byte offset of the channel chunk inside a pixel
   bool a_ok[A_LD];
-  int row_a[2];                      // the two distinct tile rows of this lane's x loads (instructions j and j+2 share a row)
+  int row_a[NROW];                   // distinct tile rows of this lane's x loads (instruction j uses row j % NROW of image j / NROW)
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int a = wave + 8 * j, sub = a >> 4, idx = a & 15;
+    const int sub = j / NROW, idx = wave + NW * (j % NROW);
     const int row = 4 * idx + lrow;
-    if (j < 2) row_a[j] = row;
+    if (j < NROW) row_a[j] = row;
     const int chunk = slot ^ ((lrow << 2) | (idx & 3));
     const int k = kp0 + sub * 128 + 8 * chunk;
     a_ok[j] = k < p.Ktot;
@@ -88,18 +92,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
   int row_b[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    const int idx = wave + 8 * j;
+    const int idx = wave + NW * j;
     row_b[j] = 4 * idx + lrow;
     const int chunk = slot ^ ((lrow << 2) | (idx & 3));
     const int co = q0 + 8 * chunk;
     b_ok[j] = co < p.Cout;
     b_off[j] = ((long)row_b[j] * p.dz_ld + (b_ok[j] ? co : 0)) * 2;
   }
-  // pixel coordinates of the two x rows at the step being issued
-  int pi[2], poh[2], pow_[2];
+  // pixel coordinates of this lane's x rows at the step being issued
+  int pi[NROW], poh[NROW], pow_[NROW];
   const long HWo = (long)p.Ho * p.Wo;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NROW; ++r) {
     long m = m_begin + row_a[r];
     if (m >= p.M) m = p.M - 1;                  // masked below through m_issue
     pi[r] = (int)(m / HWo);
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
     char* stage = smem + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int r = j & 1;
+      const int r = j % NROW;
       const bool live = a_ok[j] && (m_issue + row_a[r] < m_end);
       const char* g = zero;
       if (p.pointwise) {
@@ -123,18 +127,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
         if (live && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi)
           g = p.x + (((long)pi[r] * p.Hi + ih) * p.Wi + iw) * p.x_ld * 2 + a_coff[j];
       }
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (j / NROW) * IMG + (wave + NW * r) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const bool live = b_ok[j] && (m_issue + row_b[j] < m_end);
       const char* g = live ? p.dz + m_issue * p.dz_ld * 2 + b_off[j] : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + 2 * IMG + (wave + 8 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + NA * IMG + (wave + NW * j) * 1024), 16, 0, 0);
     }
     m_issue += BKP;
     if (!p.pointwise) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < NROW; ++r) {
         pow_[r] += BKP;
         while (pow_[r] >= p.Wo) { pow_[r] -= p.Wo; ++poh[r]; }
         while (poh[r] >= p.Ho) { poh[r] -= p.Ho; ++pi[r]; }
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int tile32 = (wn * 64 + j * 32) >> 5;
-      b_adr[j][t] = 2 * IMG + rowoff + 16 * ((4 * tile32 + 2 * blk + (tp >> 1)) ^ key) + 8 * (tp & 1);
+      b_adr[j][t] = NA * IMG + rowoff + 16 * ((4 * tile32 + 2 * blk + (tp >> 1)) ^ key) + 8 * (tp & 1);
     }
   }
   // MFMA tiles that lie completely in the channel padding of the block tile are skipped (wave-uniform)
@@ -177,12 +181,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
   for (int j = 0; j < TN; ++j) b_live[j] = q0 + wn * 64 + j * 32 < p.Cout;
 
   if (nsteps > 0) issue(0);
-  if (nsteps > 1) issue(1);
+  if (NSTAGE > 2 && nsteps > 1) issue(1);
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+    if (NSTAGE > 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < nsteps) issue((s + 2) % NSTAGE);
+    if (s + NSTAGE - 1 < nsteps) issue((s + NSTAGE - 1) % NSTAGE);
     const char* stage = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {                         // 16 pixels per MFMA
@@ -225,9 +229,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
     }
 }
 
-// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % 256][co % 128]; threads run along co (contiguous reads)
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_q, int Cout,
-                                                     int Cin, int Cin_pad, int KH, int KW, int Ktot, float* __restrict__ g) {
+// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % BP][co % 128]; threads run along co (contiguous reads)
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_q, int BP,
+                                                     int Cout, int Cin, int Cin_pad, int KH, int KW, int Ktot,
+                                                     float* __restrict__ g) {
   const int co = blockIdx.x * 32 + (threadIdx.x & 31);
   const int k = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (co >= Cout || k >= Ktot) return;
@@ -265,15 +270,9 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
                        long scratch_elems, float* g_oihw, void* stream) {
   using namespace wg2;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
-    if (e != hipSuccess) {
-      dy_set_error("wgrad_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 3;
-    }
-    configured = true;
-  }
+  // Two co-resident blocks per CU (128 x 128 tile on 4 waves, 2 stages = 64 KiB) beat one 256 x 128 block with a 3-deep ring
+  // (144 KiB) on the forward kernels (conv_v2.hip); DY_WG2_EXP=1 selects the single-block shape.
+  static const int exp_mode = getenv("DY_WG2_EXP") ? atoi(getenv("DY_WG2_EXP")) : 0;
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
   p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout_pad;
@@ -281,15 +280,29 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.M = (long)N * Ho * Wo;
   p.Ktot = KH * KW * Cin_pad;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
-  const int tiles_p = dy_cdiv(p.Ktot, BP);
+  const int bp = exp_mode == 1 ? 256 : 128;
+  const int nstage = exp_mode == 1 ? 3 : 2;
+  const int shmem = nstage * (bp / 128 + 1) * IMG;
+  const void* fn = exp_mode == 1 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<128, 2>);
+  static int configured = -1;
+  if (configured != exp_mode) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    if (e != hipSuccess) {
+      dy_set_error("wgrad_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 3;
+    }
+    configured = exp_mode;
+  }
+  const int tiles_p = dy_cdiv(p.Ktot, bp);
   p.tiles_q = dy_cdiv(Cout_pad, BQ);
   const int tiles = tiles_p * p.tiles_q;
-  // about two blocks per CU, at least 8 steps per block, and the slabs must fit the scratch buffer
-  long splits = (512 + tiles - 1) / tiles;
+  // about two waves of blocks over the chip, at least 8 steps per block, and the slabs must fit the scratch buffer
+  const long target = exp_mode == 1 ? 512 : 1024;
+  long splits = (target + tiles - 1) / tiles;
   const long max_splits = (p.M + 8L * BKP - 1) / (8L * BKP);
   if (splits > max_splits) splits = max_splits;
-  const long fit = scratch_elems / ((long)tiles * BP * BQ);
-  DY_CHECK(fit >= 1, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems, (long)tiles * BP * BQ);
+  const long fit = scratch_elems / ((long)tiles * bp * BQ);
+  DY_CHECK(fit >= 1, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems, (long)tiles * bp * BQ);
   if (splits > fit) splits = fit;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
@@ -298,9 +311,10 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   splits = (p.M + chunk - 1) / chunk;
   p.chunk = chunk;
   hipStream_t st = (hipStream_t)stream;
-  wgrad_kernel<<<dim3(tiles, (unsigned)splits), NT, SHMEM, st>>>(p);
+  if (exp_mode == 1) wgrad_kernel<256, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
+  else wgrad_kernel<128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
-  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, Cout, Cin, Cin_pad,
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, Cout, Cin, Cin_pad,
                                                                             KH, KW, p.Ktot, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;
