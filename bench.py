@@ -231,8 +231,10 @@ def main():
         dist.all_gather(hs, h)
         out["replicas_in_sync"] = bool(all(torch.equal(hs[0], t) for t in hs))
 
-    if rank == 0 and not args.no_roofline:
+    agg = None
+    if not args.no_roofline:                      # every rank runs the instrumented steps: they contain the gradient all-reduce
         agg, psteps = kernel_profile(trainer, batches)
+    if rank == 0 and agg is not None:
         tot = sum(a["ms"] for a in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
         name, a = next(((k, v) for k, v in top if v["meta_n"] == v["n"] and v["n"] > 0), top[0])

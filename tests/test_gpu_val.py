@@ -184,7 +184,7 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     env = dict(os.environ, DY_SINGLE_DEVICE="1", DY_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
-           "--imgsz", "128", "--no-roofline", "--no-cpu-baseline"]
+           "--imgsz", "128", "--no-cpu-baseline"]       # with the roofline legs: their extra steps all-reduce on every rank
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -193,3 +193,4 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
     assert out["replicas_in_sync"] is True
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
+    assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out          # cpu_baseline is an N=1 field
