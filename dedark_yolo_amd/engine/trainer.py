@@ -110,7 +110,11 @@ class GradBuckets:
     every parameterised layer of the bucket has produced its gradients (RCCL waits on the compute stream at issue time and
     runs on its own stream, so it overlaps the remaining dgrad / wgrad kernels)."""
 
-    def __init__(self, flat, model, bucket_bytes=32 << 20):
+    def __init__(self, flat, model, bucket_bytes=None):
+        # about six buckets per backward pass (so that all but the last overlap with it), capped at 32 MB: a ring all-reduce over
+        # xGMI is per-link bound, so few large messages beat many small ones, but one single bucket cannot overlap at all
+        if bucket_bytes is None:
+            bucket_bytes = min(32 << 20, max(1 << 20, flat.n * 4 // 6))
         self.flat = flat
         self.works = []
         self.buckets = []          # dict(start, end, layers)
