@@ -259,10 +259,11 @@ bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
   static const bool off = getenv("DY_NO_WGRAD_V2") != nullptr;
   if (off) return false;
   const long Ktot = (long)KH * KW * Cin_pad;
-  // half of the 128-wide co tile is idle for Cout <= 64: only worth it when the pixel loop is long (measured: 64->64 3x3 at
-  // M = 51,200 is 15 % slower than the register-staged kernel, at M = 204,800 12 % faster)
-  const long min_m = Cout_pad <= 64 ? 131072 : 4096;
-  return dtype == DY_BF16 && Cin_pad % 8 == 0 && Cout_pad % 8 == 0 && Cout_pad >= 64 && Ktot >= 128 && M >= min_m && M < (1L << 31) &&
+  // Cout <= 32 stays on the register-staged kernel (32->32 3x3 at 80x80: 59 us there, 66 us here: 3/4 of the co tile would be
+  // padding); DY_WG2_NARROW=<min Cout> overrides for experiments.
+  static const int exp_narrow = getenv("DY_WG2_NARROW") ? atoi(getenv("DY_WG2_NARROW")) : 0;
+  const int min_co = exp_narrow > 0 ? exp_narrow : 64;
+  return dtype == DY_BF16 && Cin_pad % 8 == 0 && Cout_pad % 8 == 0 && Cout_pad >= min_co && Ktot >= 64 && M >= 4096 && M < (1L << 31) &&
          (x_ld * 2) % 16 == 0 && (dz_ld * 2) % 16 == 0;
 }
 
