@@ -389,8 +389,10 @@ template <> struct Transposer<bf16_t, 8> {
   }
 };
 
+// The small tiles are latency-bound (one global-load round trip per 64-pixel step): cap them at 128 VGPRs so that four blocks
+// share a CU instead of three (they compile to 132 without the bound).
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgP p) {
+__global__ __launch_bounds__(NTHREADS, (BM * BN <= 4096 ? 4 : 1)) void conv_wgrad_kernel(WgP p) {
   constexpr int VE = DT<T>::VE;
   constexpr int MK = 8 * VE;                 // pixels per step
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
