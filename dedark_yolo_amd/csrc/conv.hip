@@ -122,8 +122,10 @@ __device__ inline void mma_step(const char* As, const char* Bs, int a_row0, int 
 // ---- forward / dgrad kernel --------------------------------------------------------------------------------------
 // MODE 0: src coord = o*stride - pad + k*dil            (forward gather)
 // MODE 1: t = o + pad - k*dil ; valid iff t % stride == 0 ; src coord = t / stride   (data gradient gather)
+// The 128x32 tile (narrow n-scale layers) is latency-bound: six co-resident blocks per CU (78-80 VGPRs, 23 KB LDS each) instead
+// of four cut the narrow forward / dgrad layers by 0.19 ms per C2 step.
 template <typename T, int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kernel(ConvP p) {
   constexpr int VE = DT<T>::VE;
   constexpr int BK = 8 * VE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
