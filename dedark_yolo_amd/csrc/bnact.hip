@@ -98,10 +98,11 @@ __device__ inline Map make_map(int C, int cgb, int rows) {
   return m;
 }
 
-constexpr int UN = 4;   // pixels in flight per thread
 
 // Per-channel constants are staged once per block in LDS (coalesced loads by the first threads) and copied to registers.
-template <typename T>
+// U = pixels in flight per thread.  More is not better: the 7 per-channel constants x VE already take 56 VGPRs in the backward
+// kernels, and occupancy beats per-thread ILP for these streams (bn_bench: apply on 64ch x 6.5 M px 531 us at U=4, 487 us at U=1).
+template <typename T, int U>
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z, long z_ld, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, const T* __restrict__ res,
                                                          long res_ld, T* __restrict__ y, long y_ld, long pixels, int C, int cgb,
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z,
     sc[e] = lds[m.cl + e];
     sh[e] = lds[nch + m.cl + e];
   }
-  for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
-    float v[UN][VE], r[UN][VE];
+  for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+    float v[U][VE], r[U][VE];
 #pragma unroll
-    for (int k = 0; k < UN; ++k) {
+    for (int k = 0; k < U; ++k) {
       const long p = p0 + k * m.step;
       if (p < pixels) {
         ldvec<T>(z + p * z_ld + m.c, v[k]);
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z,
       }
     }
 #pragma unroll
-    for (int k = 0; k < UN; ++k) {
+    for (int k = 0; k < U; ++k) {
       const long p = p0 + k * m.step;
       if (p < pixels) {
 #pragma unroll
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z,
 }
 
 // backward pass 1: per-channel sums of g and g*zhat
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
                                                                 long z_ld, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
@@ -183,10 +184,10 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
       s1[e] = 0.f;
       s2[e] = 0.f;
     }
-    for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
-      float g[UN][VE], zz[UN][VE];
+    for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+      float g[U][VE], zz[U][VE];
 #pragma unroll
-      for (int k = 0; k < UN; ++k) {
+      for (int k = 0; k < U; ++k) {
         const long p = p0 + k * m.step;
         if (p < pixels) {
           ldvec<T>(dy + p * dy_ld + m.c, g[k]);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
         }
       }
 #pragma unroll
-      for (int k = 0; k < UN; ++k) {
+      for (int k = 0; k < U; ++k) {
         const long p = p0 + k * m.step;
         if (p < pixels) {
 #pragma unroll
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
 }
 
 // backward pass 2: dz = k1*g - (K2*zhat + K3) with k1 = gamma*invstd, K2 = k1*sum(g*zhat)/M, K3 = k1*sum(g)/M
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
                                                                long z_ld, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ mean,
@@ -275,10 +276,10 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
     k2[e] = lds[5 * nch + m.cl + e];
     k3[e] = lds[6 * nch + m.cl + e];
   }
-  for (long p0 = m.first; p0 < pixels; p0 += UN * m.step) {
-    float g[UN][VE], zz[UN][VE];
+  for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+    float g[U][VE], zz[U][VE];
 #pragma unroll
-    for (int k = 0; k < UN; ++k) {
+    for (int k = 0; k < U; ++k) {
       const long p = p0 + k * m.step;
       if (p < pixels) {
         ldvec<T>(dy + p * dy_ld + m.c, g[k]);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
       }
     }
 #pragma unroll
-    for (int k = 0; k < UN; ++k) {
+    for (int k = 0; k < U; ++k) {
       const long p = p0 + k * m.step;
       if (p < pixels) {
 #pragma unroll
@@ -368,12 +369,12 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   const Geo g = geometry(pixels, C, ve, 0);
   const size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DY_F32)
-    bn_act_fwd_kernel<float><<<g.grid, NT, shm, st>>>((const float*)z, z_ld, scale, shift, act, (const float*)residual, res_ld,
-                                                    (float*)y, y_ld, pixels, C, g.cgb, g.rows);
-  else
-    bn_act_fwd_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)z, z_ld, scale, shift, act, (const bf16_t*)residual, res_ld,
-                                                     (bf16_t*)y, y_ld, pixels, C, g.cgb, g.rows);
+  const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+#define FWD(T_, U_) bn_act_fwd_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
+                                                                    (T_*)y, y_ld, pixels, C, g.cgb, g.rows)
+  if (dtype == DY_F32) { if (big) FWD(float, 4); else FWD(float, 2); }
+  else { if (big) FWD(bf16_t, 4); else FWD(bf16_t, 2); }
+#undef FWD
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -390,11 +391,11 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   size_t shm = 6 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32)
-    bn_act_bwd_reduce_kernel<float><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
-                                                             invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+    bn_act_bwd_reduce_kernel<float, 2><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
+                                                                invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
   else
-    bn_act_bwd_reduce_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                              mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+    bn_act_bwd_reduce_kernel<bf16_t, 2><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
+                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -412,14 +413,13 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   const Geo g = geometry(pixels > 0 ? pixels : 1, C, ve, 2);
   const size_t shm = 7 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DY_F32)
-    bn_act_bwd_apply_kernel<float><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean, invstd,
-                                                          gamma, act, has_bn, sums, (float*)dz, dz_ld, dgamma, dbeta, pixels,
-                                                          pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
-  else
-    bn_act_bwd_apply_kernel<bf16_t><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift, mean,
-                                                           invstd, gamma, act, has_bn, sums, (bf16_t*)dz, dz_ld, dgamma, dbeta,
-                                                           pixels, pixels > 0 ? pixels : 1, C, g.cgb, g.rows);
+  const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+#define APPLY(T_, U_) bn_act_bwd_apply_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)dy, dy_ld, (const T_*)z, z_ld, scale, shift, mean, invstd, \
+                                                                            gamma, act, has_bn, sums, (T_*)dz, dz_ld, dgamma, dbeta, pixels, \
+                                                                            pixels > 0 ? pixels : 1, C, g.cgb, g.rows)
+  if (dtype == DY_F32) { if (big) APPLY(float, 1); else APPLY(float, 2); }
+  else { if (big) APPLY(bf16_t, 1); else APPLY(bf16_t, 2); }
+#undef APPLY
   DY_LAUNCH_CHECK();
   return 0;
 }
