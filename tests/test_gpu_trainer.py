@@ -131,3 +131,28 @@ def test_train_loop_steps_optimizer_every_accumulate_batches():
     before = tr.updates
     hist = tr.train(batches, epochs=1)
     assert tr.updates - before == 2 and len(hist) == 1 and all(np.isfinite(hist[0]))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
+    """End-to-end sanity of the whole path (front-end, network, assigner, loss, backward, clip, SGD, EMA, weight re-pack):
+    120 optimizer steps on one fixed synthetic batch must drive the loss down substantially in both compute dtypes (the first
+    tens of steps are noisy: batch-4 BatchNorm and a moving assignment; measured 24 -> 7.4 in fp32)."""
+    import bench
+    import dedark_yolo_amd as dy
+    tr = _tiny_trainer("SGD", batch=64)
+    if dtype == "bf16":
+        dy.set_compute_dtype(torch.bfloat16)
+    try:
+        b = bench.synth_batch(77, 4, 96, 20, "cuda")
+        tr.args.dark_param = b.pop("gamma")
+        b.pop("n_max")
+        losses = []
+        for _ in range(120):
+            loss, _ = tr.train_step(dict(b), [0.01] * 3, 0.9)
+            losses.append(float(loss))
+        assert all(np.isfinite(losses)), losses
+        first, last = float(np.mean(losses[:10])), float(np.mean(losses[-10:]))
+        assert last < 0.6 * first, (first, last)
+    finally:
+        dy.set_compute_dtype(torch.float32)
