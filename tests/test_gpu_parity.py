@@ -315,3 +315,34 @@ def test_full_size_properties():
     conv.bn.running_mean.zero_()          # pure linear map
     with torch.no_grad():
         close((conv(a) + conv(b)).cpu(), conv(a + b).cpu(), 1e-4, 1e-4, "conv linearity")
+
+
+@pytest.mark.parametrize("case", ["one_image_empty", "no_boxes"])
+def test_loss_with_empty_targets_vs_oracle(case):
+    """Ragged / empty label sets (reference loss.py:125-140 preprocess handles images without boxes; with no boxes at all only
+    the classification term and the recovery term remain)."""
+    from parity_helpers import build_models
+    from oracle import loss as oloss
+    from oracle import model as om
+    model, (plan, save, sd) = build_models("yolov8-lowlight.yaml", "t", [0.33, 0.125, 1024], 5)
+    S, B = 64, 3
+    img = rnd(41, B, 3, S, S)
+    if case == "one_image_empty":
+        bi, cls, bb = [0, 0, 2], [1, 3, 5], [[.5, .5, .3, .4], [.3, .6, .2, .2], [.6, .4, .5, .5]]
+    else:
+        bi, cls, bb = [], [], []
+    batch = dict(img=img.clone(), batch_idx=torch.tensor(bi, dtype=torch.float32), cls=torch.tensor(cls, dtype=torch.float32).view(-1, 1),
+                 bboxes=torch.tensor(bb, dtype=torch.float32).view(-1, 4), recovery_loss_batch=torch.tensor(0.01))
+    gb = {k: v.cuda() for k, v in batch.items()}
+    model.train()
+    loss, items = model(gb)
+    loss.backward()
+    torch.cuda.synchronize()
+    maps = om.forward(plan, save, {k: v.detach().clone() for k, v in sd.items()}, batch["img"], True)
+    strides = [float(S // m.shape[2]) for m in maps]
+    ol, oi = oloss.recovery_detection_loss(maps, batch, strides, 20, oloss.default_hyp())
+    close(loss.detach().cpu(), ol.detach(), 1e-4, 1e-4, f"{case} loss")
+    close(items.detach().cpu(), oi.detach(), 1e-4, 1e-4, f"{case} items")
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    if case == "no_boxes":
+        assert float(items[0]) == 0.0 and float(items[2]) == 0.0
