@@ -22,7 +22,7 @@
 
 namespace wg2 {
 
-constexpr int BQ = 128, BKP = 64;
+constexpr int BKP = 64;
 constexpr int IMG = BKP * 256;                 // one [64][128ch] image: 16 KiB
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -49,14 +49,15 @@ struct P {
 };
 
 // BP (k') x 128 (co) block tile on (BP/64) x 2 waves, 64 x 64 outputs per wave, NSTAGE-deep ring of (BP/128 + 1) images.
-template <int BP, int NSTAGE>
+template <int BP, int BQ, int NSTAGE>
 __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
-  constexpr int TM = 2, TN = 2;
+  constexpr int TM = 2, TN = BQ / 64;            // wave tile 64 (k') x BQ/2 (co)
   constexpr int NA = BP / 128;                   // x images per stage
+  constexpr int NBI = BQ / 128;                  // dz images per stage
   constexpr int NW = BP / 32;                    // waves
   constexpr int NROW = 16 / NW;                  // distinct tile rows per lane inside one image (4 rows per wave instruction)
-  constexpr int A_LD = NA * NROW, B_LD = NROW;   // global_load_lds per lane and stage
-  constexpr int STAGE = (NA + 1) * IMG;
+  constexpr int A_LD = NA * NROW, B_LD = NBI * NROW;   // global_load_lds per lane and stage
+  constexpr int STAGE = (NA + NBI) * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
   int row_b[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    const int idx = wave + NW * j;
+    const int idx = wave + NW * (j % NROW);
     row_b[j] = 4 * idx + lrow;
     const int chunk = slot ^ ((lrow << 2) | (idx & 3));
-    const int co = q0 + 8 * chunk;
+    const int co = q0 + (j / NROW) * 128 + 8 * chunk;
     b_ok[j] = co < p.Cout;
     b_off[j] = ((long)row_b[j] * p.dz_ld + (b_ok[j] ? co : 0)) * 2;
   }
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
     for (int j = 0; j < B_LD; ++j) {
       const bool live = b_ok[j] && (m_issue + row_b[j] < m_end);
       const char* g = live ? p.dz + m_issue * p.dz_ld * 2 + b_off[j] : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + NA * IMG + (wave + NW * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(stage + (NA + j / NROW) * IMG + (wave + NW * (j % NROW)) * 1024), 16, 0, 0);
     }
     m_issue += BKP;
     if (!p.pointwise) {
@@ -169,8 +170,9 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int tile32 = (wn * 64 + j * 32) >> 5;
-      b_adr[j][t] = NA * IMG + rowoff + 16 * ((4 * tile32 + 2 * blk + (tp >> 1)) ^ key) + 8 * (tp & 1);
+      const int ncol = wn * (BQ / 2) + j * 32;               // first co of the MFMA tile inside the BQ-wide block tile
+      const int tile32 = (ncol & 127) >> 5;
+      b_adr[j][t] = (NA + (ncol >> 7)) * IMG + rowoff + 16 * ((4 * tile32 + 2 * blk + (tp >> 1)) ^ key) + 8 * (tp & 1);
     }
   }
   // MFMA tiles that lie completely in the channel padding of the block tile are skipped (wave-uniform)
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) a_live[i] = kp0 + wm * 64 + i * 32 < p.Ktot;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b_live[j] = q0 + wn * 64 + j * 32 < p.Cout;
+  for (int j = 0; j < TN; ++j) b_live[j] = q0 + wn * (BQ / 2) + j * 32 < p.Cout;
 
   if (nsteps > 0) issue(0);
   if (NSTAGE > 2 && nsteps > 1) issue(1);
@@ -222,15 +224,15 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if (!(a_live[i] && b_live[j])) continue;               // the reduce kernel never reads padding tiles
-      const int col = wn * 64 + j * 32 + cl;
+      const int col = wn * (BQ / 2) + j * 32 + cl;
       const int row0 = wm * 64 + i * 32 + 4 * hh;
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2)) * BQ + col] = acc[i][j][r];
     }
 }
 
-// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % BP][co % 128]; threads run along co (contiguous reads)
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_q, int BP,
+// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % BP][co % BQ]; threads run along co (contiguous reads)
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_q, int BP, int BQ,
                                                      int Cout, int Cin, int Cin_pad, int KH, int KW, int Ktot,
                                                      float* __restrict__ g) {
   const int co = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -271,9 +273,12 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
                        long scratch_elems, float* g_oihw, void* stream) {
   using namespace wg2;
-  // Two co-resident blocks per CU (128 x 128 tile on 4 waves, 2 stages = 64 KiB) beat one 256 x 128 block with a 3-deep ring
-  // (144 KiB) on the forward kernels (conv_v2.hip); DY_WG2_EXP=1 selects the single-block shape.
-  static const int exp_mode = getenv("DY_WG2_EXP") ? atoi(getenv("DY_WG2_EXP")) : 0;
+  // Tile choice (tools/conv_bench, B = 64).  The kernel streams its operands from L2 / Infinity Cache every step, so the tile's
+  // flop-per-byte decides: 256 x 256 (128 flop/B, 128 KiB, one block per CU) when the layer has >= 256 output channels
+  // (256->256 3x3 at 40x40: 271 -> 200 us = 604 TF; 256->512 3x3 s2: 567 -> 386 us), otherwise 128 x 128 on 4 waves with two
+  // co-resident blocks (64 KiB each), which beats 256 x 128 x 3 stages.  DY_WG2_EXP = 1 / 2 / 3 forces 256x128x3 / 256x256 / 128x128.
+  static const int exp_env = getenv("DY_WG2_EXP") ? atoi(getenv("DY_WG2_EXP")) : 0;
+  const int exp_mode = exp_env == 3 ? 0 : (exp_env > 0 ? exp_env : (Cout_pad >= 256 ? 2 : 0));
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
   p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout_pad;
@@ -281,24 +286,27 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.M = (long)N * Ho * Wo;
   p.Ktot = KH * KW * Cin_pad;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
-  const int bp = exp_mode == 1 ? 256 : 128;
+  const int bp = (exp_mode == 1 || exp_mode == 2) ? 256 : 128;
+  const int BQ = exp_mode == 2 ? 256 : 128;
   const int nstage = exp_mode == 1 ? 3 : 2;
-  const int shmem = nstage * (bp / 128 + 1) * IMG;
-  const void* fn = exp_mode == 1 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<128, 2>);
-  static int configured = -1;
-  if (configured != exp_mode) {
+  const int shmem = nstage * (bp / 128 + BQ / 128) * IMG;
+  const void* fn = exp_mode == 1 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 128, 3>)
+                 : exp_mode == 2 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 256, 2>)
+                                 : reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>);
+  static int configured = 0;          // bit mask of the variants whose LDS limit has been raised
+  if (!(configured & (1 << exp_mode))) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     if (e != hipSuccess) {
       dy_set_error("wgrad_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
     }
-    configured = exp_mode;
+    configured |= 1 << exp_mode;
   }
   const int tiles_p = dy_cdiv(p.Ktot, bp);
   p.tiles_q = dy_cdiv(Cout_pad, BQ);
   const int tiles = tiles_p * p.tiles_q;
   // about two waves of blocks over the chip, at least 8 steps per block, and the slabs must fit the scratch buffer
-  const long target = exp_mode == 1 ? 512 : 1024;
+  const long target = (exp_mode == 1 || exp_mode == 2) ? 512 : 1024;
   long splits = (target + tiles - 1) / tiles;
   const long max_splits = (p.M + 8L * BKP - 1) / (8L * BKP);
   if (splits > max_splits) splits = max_splits;
@@ -312,10 +320,11 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   splits = (p.M + chunk - 1) / chunk;
   p.chunk = chunk;
   hipStream_t st = (hipStream_t)stream;
-  if (exp_mode == 1) wgrad_kernel<256, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
-  else wgrad_kernel<128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
+  if (exp_mode == 1) wgrad_kernel<256, 128, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
+  else if (exp_mode == 2) wgrad_kernel<256, 256, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
+  else wgrad_kernel<128, 128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
-  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, Cout, Cin, Cin_pad,
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, BQ, Cout, Cin, Cin_pad,
                                                                             KH, KW, p.Ktot, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;
