@@ -292,7 +292,9 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(P p) {
 
 template <int BN, int MODE, bool SMALLC, int NSTAGE = 3, int BM = 256>
 int launch(P& p, hipStream_t st) {
-  constexpr int SHMEM = NSTAGE * (BM + BN) * ROW;
+  constexpr int RING = NSTAGE * (BM + BN) * ROW, EPI = dy_epi::image_bytes<BM, BN>();
+  constexpr int SHMEM = RING > EPI ? RING : EPI;            // the epilogue image reuses the ring
+  static_assert(SHMEM <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BM, BN, MODE, SMALLC, NSTAGE>),
@@ -315,6 +317,13 @@ int launch(P& p, hipStream_t st) {
 // true when the pipelined kernel can take this problem (the dispatcher in conv.hip falls back to the generic kernel otherwise)
 extern "C" int dy_debug_conv_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(v2::g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+
+// 256 x 256 tiles pay off only when they still fill the chip (256 CUs, one block each): 256->256 3x3 at 20x20 with B = 64 is just
+// 100 such tiles and ran at 93 us against 56 us on the band kernel.
+bool dy_conv_prefers_256(const dy_conv_desc* d) {
+  const long M = (long)d->N * d->Hd * d->Wd;
+  return d->Cd >= 256 && ((M + 255) / 256) * ((d->Cd + 255) / 256) >= 192;
 }
 
 bool dy_conv_v2_eligible(const dy_conv_desc* d) {
@@ -362,6 +371,9 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   static const int exp_mode = getenv("DY_V2_EXP") ? atoi(getenv("DY_V2_EXP")) : 0;
 #define DY_V2_GO(BN_, NS_, BM_) (mode == 0 ? v2::launch<BN_, 0, false, NS_, BM_>(p, st) : v2::launch<BN_, 1, false, NS_, BM_>(p, st))
   if (exp_mode == 1) return wide ? DY_V2_GO(128, 3, 256) : DY_V2_GO(64, 3, 256);        // the first version: one block per CU
+  // >= 256 output channels: 256 x 256 tile (one block per CU, 2 stages = 128 KiB).  These kernels stream both operands from L2 /
+  // Infinity Cache every step, so the tile's flop-per-byte (128 vs 64 for 128 x 128) outweighs co-residency here.
+  if (dy_conv_prefers_256(d) && exp_mode != 2) return DY_V2_GO(256, 2, 256);
   return wide ? DY_V2_GO(128, 2, 128) : DY_V2_GO(64, 2, 256);
 #undef DY_V2_GO
 }
