@@ -374,6 +374,7 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   // >= 256 output channels: 256 x 256 tile (one block per CU, 2 stages = 128 KiB).  These kernels stream both operands from L2 /
   // Infinity Cache every step, so the tile's flop-per-byte (128 vs 64 for 128 x 128) outweighs co-residency here.
   if (dy_conv_prefers_256(d) && exp_mode != 2) return DY_V2_GO(256, 2, 256);
+  if (exp_mode == 3 && wide) return DY_V2_GO(128, 2, 512);      // experiment: 512 x 128 tile on 16 waves, exactly 160 KiB
   return wide ? DY_V2_GO(128, 2, 128) : DY_V2_GO(64, 2, 256);
 #undef DY_V2_GO
 }

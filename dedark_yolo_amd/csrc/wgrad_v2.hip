@@ -286,12 +286,13 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.M = (long)N * Ho * Wo;
   p.Ktot = KH * KW * Cin_pad;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
-  const int bp = (exp_mode == 1 || exp_mode == 2) ? 256 : 128;
+  const int bp = (exp_mode == 1 || exp_mode == 2 || exp_mode == 4) ? 256 : 128;
   const int BQ = exp_mode == 2 ? 256 : 128;
-  const int nstage = exp_mode == 1 ? 3 : 2;
+  const int nstage = exp_mode == 1 ? 3 : 2;      // exp_mode 4: 256 x 128 x 2 stages (96 KiB)
   const int shmem = nstage * (bp / 128 + BQ / 128) * IMG;
   const void* fn = exp_mode == 1 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 128, 3>)
                  : exp_mode == 2 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 256, 2>)
+                 : exp_mode == 4 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 128, 2>)
                                  : reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>);
   static int configured = 0;          // bit mask of the variants whose LDS limit has been raised
   if (!(configured & (1 << exp_mode))) {
@@ -306,7 +307,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.tiles_q = dy_cdiv(Cout_pad, BQ);
   const int tiles = tiles_p * p.tiles_q;
   // about two waves of blocks over the chip, at least 8 steps per block, and the slabs must fit the scratch buffer
-  const long target = (exp_mode == 1 || exp_mode == 2) ? 512 : 1024;
+  const long target = (exp_mode == 1 || exp_mode == 2 || exp_mode == 4) ? 512 : 1024;
   long splits = (target + tiles - 1) / tiles;
   const long max_splits = (p.M + 8L * BKP - 1) / (8L * BKP);
   if (splits > max_splits) splits = max_splits;
@@ -322,6 +323,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   hipStream_t st = (hipStream_t)stream;
   if (exp_mode == 1) wgrad_kernel<256, 128, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
   else if (exp_mode == 2) wgrad_kernel<256, 256, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
+  else if (exp_mode == 4) wgrad_kernel<256, 128, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
   else wgrad_kernel<128, 128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
   reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, BQ, Cout, Cin, Cin_pad,
