@@ -59,8 +59,11 @@ class _ModuleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         gouts = [g if g is not None else torch.zeros(m[0], dtype=m[1], device=m[2]) for g, m in zip(gouts, ctx.out_meta)]
-        gouts = [as_nhwc(g, m[1]) for g, m in zip(gouts, ctx.out_meta)]
         module, tape = ctx.module, ctx.tape
+        if getattr(module, "_planar_grad_ok", False) and all(g.is_contiguous() and g.dtype == m[1] for g, m in zip(gouts, ctx.out_meta)):
+            pass             # the module's backward consumes planar [B,C,H,W] gradients as they are (front-end <- direct stem dgrad)
+        else:
+            gouts = [as_nhwc(g, m[1]) for g, m in zip(gouts, ctx.out_meta)]
         gins = module._bwd(tape, *gouts, needs=list(ctx.needs_input_grad[2:2 + ctx.n_in]))
         if not isinstance(gins, (list, tuple)):
             gins = (gins,)
@@ -537,6 +540,8 @@ class lowlight_recovery(DyModule):
     NHWC8 buffer in the compute dtype, consumed in place by the stem conv).  All filter math is fp32.
     """
     in_dtype = torch.float32
+
+    _planar_grad_ok = True          # _bwd takes the planar gradient written by the direct stem dgrad kernel
 
     def __init__(self, in_channels=3, out_channels=3):
         super().__init__()
