@@ -1,0 +1,221 @@
+// Band weight gradient for the 64-channel 3x3 / stride 1 / pad 1 layers (Bottleneck convs of the C2f blocks, reference
+// ultralytics/nn/modules/block.py:553-565), bf16.
+//
+// These layers are bandwidth-bound (64->64 at 160x160, B = 64: 420 MB of operands for 121 GFLOP), yet the tiled kernels re-read
+// x once per tap and dz once per k'-tile through L2 (4-5x the algorithmic traffic by the PMC counters) and run at 190-210 TF.
+// Here a block walks over consecutive rows of ONE image and keeps, in a zero-padded pixel space,
+//     x rows h-1, h, h+1 (+ the row being prefetched)  in a 4-slot ring of LDS row buffers [pixel][64 ci]
+//     dz row h (+ the next one)                        in 2 row buffers               [pixel][64 co]
+// so that every operand byte is fetched from HBM exactly once and all 9 taps are shifted windows of the same LDS rows:
+//     D[(kh,kw,ci)][co] += sum_px  x_pad[h+kh-1][px+kw-1][ci] * dz_pad[h][px][co]
+// The zero padding (one pixel left / right, zero rows above / below the image) is produced by the DMA itself (padding lanes
+// fetch a zero page), so there are no border masks anywhere.  Operands are read with ds_read_b64_tr_b16 (pixel-major LDS rows
+// -> 8 consecutive pixels of one channel per lane).  6 waves: wave w owns k' tiles 3w..3w+2 (of 18 = 9 taps x 2 ci tiles) x both
+// co tiles = 6 accumulator tiles; 10 transposing reads per 6 MFMA.  One barrier per image row.
+// Partial sums go to `scratch` as [block][576][64] f32 and are reduced by wg2's deterministic reduce kernel layout.
+#include <stdlib.h>
+#include "dy_common.h"
+#include "../../include/dedark_yolo.h"
+
+namespace wg3 {
+
+constexpr int CH = 64;                    // channels (both sides), 128-byte LDS pixels
+constexpr int PXB = CH * 2;               // bytes per pixel
+constexpr int NT = 384;                   // 6 waves
+constexpr int KT = 18;                    // k' tiles of 32: (tap, ci half)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[16];
+
+struct P {
+  const char* x;
+  long x_ld;
+  const char* dz;
+  long dz_ld;
+  int N, H, W;
+  int PW;          // padded pixels per row processed by the MFMAs (multiple of 16, >= W + 2)
+  int XW;          // pixel slots per x row buffer (PW + 8): slot j holds padded column j - 1, i.e. image column j - 2
+  int rb, nseg;    // rows per block, blocks per image
+  float* part;     // [blocks][576][64]
+};
+
+// one image row -> one LDS row buffer; `shift` = slot index of image column 0 (2 for x, 1 for dz); rows outside the image and
+// slots outside [shift, shift + W) come from the zero page
+__device__ inline void load_row(const char* src, long ld, int n, int h, int H, int W, char* buf, int slots, int shift, int wave, int lane,
+                                const char* zero) {
+  const int ninstr = slots >> 3;                        // 8 pixels (1 KiB) per wave instruction
+  const bool rowok = h >= 0 && h < H;
+  const int pl = lane >> 3, chunk = lane & 7;
+  for (int i = wave; i < ninstr; i += NT / 64) {
+    const int w = 8 * i + pl - shift;
+    const char* g = (rowok && w >= 0 && w < W) ? src + ((((long)n * H + h) * W + w) * ld + chunk * 8) * 2 : zero;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + i * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int XB = p.XW * PXB, ZB = p.PW * PXB;           // bytes per x / dz row buffer
+  char* xring = smem;                                   // 4 x rows
+  char* zring = smem + 4 * XB;                          // 2 dz rows
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int n = blockIdx.x / p.nseg, seg = blockIdx.x - n * p.nseg;
+  const int h0 = seg * p.rb, h1 = min(h0 + p.rb, p.H);
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane part of the transposed-read addresses: lane 4q+p of a 16-lane group addresses pixel q of a 4-pixel block, channels
+  // 4p..4p+3 of the group's 16-channel block; lanes 0-31 / 32-63 take pixels 0-7 / 8-15 of the 16-pixel slice
+  const int g4 = lane >> 4, hh = g4 >> 1, blk = g4 & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int lane_off = (8 * hh + tq) * PXB + blk * 32 + tp * 8;
+  int a_kh[3], a_off[3];                                // tile -> ring row selector and byte offset (tap column + ci half)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int kt = 3 * wave + i, tap = kt >> 1, ct = kt & 1;
+    a_kh[i] = tap / 3;
+    a_off[i] = (tap - 3 * a_kh[i]) * PXB + ct * 64 + lane_off;      // x slot index = px + kw
+  }
+  const int b_off[2] = {lane_off, 64 + lane_off};
+
+  // slot of image row r in the x ring: (r + 1) & 3
+  load_row(p.x, p.x_ld, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row(p.x, p.x_ld, n, h0, p.H, p.W, xring + ((h0 + 1) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row(p.x, p.x_ld, n, h0 + 1, p.H, p.W, xring + ((h0 + 2) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row(p.dz, p.dz_ld, n, h0, p.H, p.W, zring + (h0 & 1) * ZB, p.PW, 1, wave, lane, zero);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int nslices = p.PW >> 4;
+  for (int h = h0; h < h1; ++h) {
+    if (h + 1 < h1) {                                    // prefetch what the next row needs
+      load_row(p.x, p.x_ld, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero);
+      load_row(p.dz, p.dz_ld, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero);
+    }
+    const char* xa[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xa[i] = xring + ((h + a_kh[i]) & 3) * XB + a_off[i];       // x row h + kh - 1
+    const char* zb = zring + (h & 1) * ZB;
+    for (int s = 0; s < nslices; ++s) {
+      const int so = s * 16 * PXB;
+      s16x8 af[3], bf[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xa[i] + so));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xa[i] + so + 4 * PXB));
+        af[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + so));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + so + 4 * PXB));
+        bf[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // D layout of the 32x32 MFMA: col (co) = lane&31, row (k') = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = p.part + (long)blockIdx.x * (KT * 32 * CH);
+  const int cl = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row0 = (3 * wave + i) * 32 + 4 * h5, col = j * 32 + cl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2)) * CH + col] = acc[i][j][r];
+    }
+}
+
+// g[co][ci][kh][kw] = sum over blocks of part[block][(kh*3+kw)*64 + ci][co]; threads run along co (contiguous reads)
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblk, int Cout, int Cin, float* __restrict__ g) {
+  const int co = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int k = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (co >= Cout || k >= KT * 32) return;
+  const int tap = k / CH, ci = k - tap * CH;
+  if (ci >= Cin) return;
+  const float* src = part + (long)k * CH + co;
+  const long sstride = (long)KT * 32 * CH;
+  float a = 0.f;
+  int s = 0;
+  for (; s + 4 <= nblk; s += 4) {
+    const float v0 = src[(long)s * sstride], v1 = src[(long)(s + 1) * sstride], v2 = src[(long)(s + 2) * sstride],
+                v3 = src[(long)(s + 3) * sstride];
+    a += (v0 + v1) + (v2 + v3);
+  }
+  for (; s < nblk; ++s) a += src[(long)s * sstride];
+  g[((long)co * Cin + ci) * 9 + tap] = a;
+}
+
+}  // namespace wg3
+
+bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
+                          long x_ld, long dz_ld, long scratch_elems) {
+  static const bool off = getenv("DY_NO_WGRAD_V3") != nullptr;
+  if (off) return false;
+  if (!(dtype == DY_BF16 && Cin_pad == 64 && Cout_pad == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1)) return false;
+  if ((x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
+  const int PW = (Wi + 2 + 15) / 16 * 16;
+  if ((4 * (PW + 8) + 2 * PW) * wg3::PXB > 160 * 1024) return false;          // the six row buffers must fit LDS
+  // worth it when the pixel loop is long enough to amortise the 147 KB slab per block (64->64 at 40x40, B = 32 is not)
+  static const long min_m = getenv("DY_WG3_MINM") ? atol(getenv("DY_WG3_MINM")) : 131072;
+  return (long)N * Hi * Wi >= min_m && scratch_elems >= 64L * wg3::KT * 32 * wg3::CH;
+}
+
+int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, const void* dz, long dz_ld, int Cout, int Cin, float* scratch,
+                       long scratch_elems, float* g_oihw, void* stream) {
+  using namespace wg3;
+  P p;
+  p.x = (const char*)x; p.x_ld = x_ld; p.dz = (const char*)dz; p.dz_ld = dz_ld;
+  p.N = N; p.H = Hi; p.W = Wi;
+  p.PW = (Wi + 2 + 15) / 16 * 16;
+  p.XW = p.PW + 8;
+  p.part = scratch;
+  // about 512 blocks, whole rows of one image each, and the slabs must fit the scratch buffer
+  const long slab = (long)KT * 32 * CH;
+  long target = 512;
+  if (target > scratch_elems / slab) target = scratch_elems / slab;
+  int nseg = (int)((target + N - 1) / N);
+  if (nseg < 1) nseg = 1;
+  if (nseg > Hi) nseg = Hi;
+  p.rb = (Hi + nseg - 1) / nseg;
+  p.nseg = (Hi + p.rb - 1) / p.rb;
+  const int nblk = N * p.nseg;
+  DY_CHECK((long)nblk * slab <= scratch_elems, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems, (long)nblk * slab);
+  const int shmem = (4 * p.XW + 2 * p.PW) * PXB;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      dy_set_error("wgrad_v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 3;
+    }
+    configured = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  wgrad_kernel<<<nblk, NT, shmem, st>>>(p);
+  DY_LAUNCH_CHECK();
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), KT * 32 / 8), 256, 0, st>>>(scratch, nblk, Cout, Cin, g_oihw);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
