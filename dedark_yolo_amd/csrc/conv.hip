@@ -38,8 +38,8 @@ int dy_dense_wgrad_launch(const void* x, long x_ld, int N, int Hi, int Wi, int C
 // band weight gradient for the 64-channel 3x3 layers (wgrad_v3.hip)
 bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
                           long x_ld, long dz_ld, long scratch_elems);
-int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, const void* dz, long dz_ld, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream);
+int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
+                       int Cin, float* scratch, long scratch_elems, float* g_oihw, void* stream);
 // direct stem kernels (conv_small.hip)
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
 int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream);
@@ -843,7 +843,7 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   if (dy_dense_wgrad_eligible(Hi, Wi, Ho, Wo, KH, KW, pad, dil))
     return dy_dense_wgrad_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout, Cin, g_oihw, dtype, stream);
   if (dy_wgrad_v3_eligible(dtype, Cin_pad, Cout_pad, KH, KW, stride, pad, dil, N, Hi, Wi, x_ld, dz_ld, scratch_elems))
-    return dy_wgrad_v3_launch(x, x_ld, N, Hi, Wi, dz, dz_ld, Cout, Cin, scratch, scratch_elems, g_oihw, stream);
+    return dy_wgrad_v3_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout_pad, Cout, Cin, scratch, scratch_elems, g_oihw, stream);
   if (dy_wgrad_v2_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, x_ld, dz_ld))
     return dy_wgrad_v2_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
                               scratch_elems, g_oihw, stream);

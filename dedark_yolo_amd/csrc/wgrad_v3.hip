@@ -1,5 +1,5 @@
-// Band weight gradient for the 64-channel 3x3 / stride 1 / pad 1 layers (Bottleneck convs of the C2f blocks, reference
-// ultralytics/nn/modules/block.py:553-565), bf16.
+// Band weight gradient for the 64- and 128-channel 3x3 / stride 1 / pad 1 layers (Bottleneck convs of the C2f blocks,
+// reference ultralytics/nn/modules/block.py:553-565), bf16.
 //
 // These layers are bandwidth-bound (64->64 at 160x160, B = 64: 420 MB of operands for 121 GFLOP), yet the tiled kernels re-read
 // x once per tap and dz once per k'-tile through L2 (4-5x the algorithmic traffic by the PMC counters) and run at 190-210 TF.
@@ -11,18 +11,17 @@
 // The zero padding (one pixel left / right, zero rows above / below the image) is produced by the DMA itself (padding lanes
 // fetch a zero page), so there are no border masks anywhere.  Operands are read with ds_read_b64_tr_b16 (pixel-major LDS rows
 // -> 8 consecutive pixels of one channel per lane).  6 waves: wave w owns k' tiles 3w..3w+2 (of 18 = 9 taps x 2 ci tiles) x both
-// co tiles = 6 accumulator tiles; 10 transposing reads per 6 MFMA.  One barrier per image row.
-// Partial sums go to `scratch` as [block][576][64] f32 and are reduced by wg2's deterministic reduce kernel layout.
+// co tiles = 6 accumulator tiles; 10 transposing reads per 6 MFMA.  One barrier per image row.  With 128 input channels there are
+// 36 k' tiles on 12 waves; every block covers 64 output channels (blockIdx.y selects the 64-wide slice of dz).
+// Partial sums go to `scratch` as [co slice][block][9*CI][64] f32 and a second kernel adds them in a fixed order.
 #include <stdlib.h>
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
 namespace wg3 {
 
-constexpr int CH = 64;                    // channels (both sides), 128-byte LDS pixels
-constexpr int PXB = CH * 2;               // bytes per pixel
-constexpr int NT = 384;                   // 6 waves
-constexpr int KT = 18;                    // k' tiles of 32: (tap, ci half)
+constexpr int CO = 64;                    // output channels per block
+constexpr int ZPB = CO * 2;               // bytes per dz pixel in LDS
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -41,27 +40,38 @@ struct P {
   int PW;          // padded pixels per row processed by the MFMAs (multiple of 16, >= W + 2)
   int XW;          // pixel slots per x row buffer (PW + 8): slot j holds padded column j - 1, i.e. image column j - 2
   int rb, nseg;    // rows per block, blocks per image
-  float* part;     // [blocks][576][64]
+  int co_stride;   // unused padding guard (kept zero)
+  float* part;     // [co slices][blocks][9*CI][64]
 };
 
 // one image row -> one LDS row buffer; `shift` = slot index of image column 0 (2 for x, 1 for dz); rows outside the image and
 // slots outside [shift, shift + W) come from the zero page
-__device__ inline void load_row(const char* src, long ld, int n, int h, int H, int W, char* buf, int slots, int shift, int wave, int lane,
-                                const char* zero) {
-  const int ninstr = slots >> 3;                        // 8 pixels (1 KiB) per wave instruction
+// C = channels per LDS pixel (64 or 128), NW = waves of the block, c0 = first channel fetched
+template <int C, int NW>
+__device__ inline void load_row(const char* src, long ld, int c0, int n, int h, int H, int W, char* buf, int slots, int shift, int wave,
+                                int lane, const char* zero) {
+  constexpr int PPI = 512 / C;                          // pixels per wave instruction (1 KiB)
+  constexpr int CPP = C / 8;                            // 16-byte chunks per pixel
+  const int ninstr = slots / PPI;
   const bool rowok = h >= 0 && h < H;
-  const int pl = lane >> 3, chunk = lane & 7;
-  for (int i = wave; i < ninstr; i += NT / 64) {
-    const int w = 8 * i + pl - shift;
-    const char* g = (rowok && w >= 0 && w < W) ? src + ((((long)n * H + h) * W + w) * ld + chunk * 8) * 2 : zero;
+  const int pl = lane / CPP, chunk = lane % CPP;
+  for (int i = wave; i < ninstr; i += NW) {
+    const int w = PPI * i + pl - shift;
+    const char* g = (rowok && w >= 0 && w < W) ? src + ((((long)n * H + h) * W + w) * ld + c0 + chunk * 8) * 2 : zero;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + i * 1024), 16, 0, 0);
   }
 }
 
-__global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
+template <int CI>
+__global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
+  constexpr int PXB = CI * 2;                           // bytes per x pixel in LDS
+  constexpr int CT = CI / 32;                           // ci tiles per tap
+  constexpr int KT = 9 * CT;                            // k' tiles of 32
+  constexpr int NW = KT / 3;                            // waves (3 k' tiles x 2 co tiles each)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int XB = p.XW * PXB, ZB = p.PW * PXB;           // bytes per x / dz row buffer
+  const int XB = p.XW * PXB, ZB = p.PW * ZPB;           // bytes per x / dz row buffer
+  const int co0 = blockIdx.y * CO;
   char* xring = smem;                                   // 4 x rows
   char* zring = smem + 4 * XB;                          // 2 dz rows
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -79,36 +89,37 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
   // per-lane part of the transposed-read addresses: lane 4q+p of a 16-lane group addresses pixel q of a 4-pixel block, channels
   // 4p..4p+3 of the group's 16-channel block; lanes 0-31 / 32-63 take pixels 0-7 / 8-15 of the 16-pixel slice
   const int g4 = lane >> 4, hh = g4 >> 1, blk = g4 & 1, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int lane_off = (8 * hh + tq) * PXB + blk * 32 + tp * 8;
-  int a_kh[3], a_off[3];                                // tile -> ring row selector and byte offset (tap column + ci half)
+  const int lane_x = (8 * hh + tq) * PXB + blk * 32 + tp * 8;
+  const int lane_z = (8 * hh + tq) * ZPB + blk * 32 + tp * 8;
+  int a_kh[3], a_off[3];                                // tile -> ring row selector and byte offset (tap column + ci tile)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int kt = 3 * wave + i, tap = kt >> 1, ct = kt & 1;
+    const int kt = 3 * wave + i, tap = kt / CT, ct = kt - tap * CT;
     a_kh[i] = tap / 3;
-    a_off[i] = (tap - 3 * a_kh[i]) * PXB + ct * 64 + lane_off;      // x slot index = px + kw
+    a_off[i] = (tap - 3 * a_kh[i]) * PXB + ct * 64 + lane_x;        // x slot index = px + kw
   }
-  const int b_off[2] = {lane_off, 64 + lane_off};
+  const int b_off[2] = {lane_z, 64 + lane_z};
 
   // slot of image row r in the x ring: (r + 1) & 3
-  load_row(p.x, p.x_ld, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row(p.x, p.x_ld, n, h0, p.H, p.W, xring + ((h0 + 1) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row(p.x, p.x_ld, n, h0 + 1, p.H, p.W, xring + ((h0 + 2) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row(p.dz, p.dz_ld, n, h0, p.H, p.W, zring + (h0 & 1) * ZB, p.PW, 1, wave, lane, zero);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0, p.H, p.W, xring + ((h0 + 1) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 + 1, p.H, p.W, xring + ((h0 + 2) & 3) * XB, p.XW, 2, wave, lane, zero);
+  load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h0, p.H, p.W, zring + (h0 & 1) * ZB, p.PW, 1, wave, lane, zero);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const int nslices = p.PW >> 4;
   for (int h = h0; h < h1; ++h) {
     if (h + 1 < h1) {                                    // prefetch what the next row needs
-      load_row(p.x, p.x_ld, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero);
-      load_row(p.dz, p.dz_ld, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero);
+      load_row<CI, NW>(p.x, p.x_ld, 0, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero);
+      load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero);
     }
     const char* xa[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) xa[i] = xring + ((h + a_kh[i]) & 3) * XB + a_off[i];       // x row h + kh - 1
     const char* zb = zring + (h & 1) * ZB;
     for (int s = 0; s < nslices; ++s) {
-      const int so = s * 16 * PXB;
+      const int so = s * 16 * PXB, sz = s * 16 * ZPB;
       s16x8 af[3], bf[2];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -118,8 +129,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + so));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + so + 4 * PXB));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + sz));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + sz + 4 * ZPB));
         bf[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
   }
 
   // D layout of the 32x32 MFMA: col (co) = lane&31, row (k') = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* out = p.part + (long)blockIdx.x * (KT * 32 * CH);
+  float* out = p.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (KT * 32 * CO);
   const int cl = lane & 31, h5 = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -143,27 +154,27 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(P p) {
     for (int j = 0; j < 2; ++j) {
       const int row0 = (3 * wave + i) * 32 + 4 * h5, col = j * 32 + cl;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2)) * CH + col] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2)) * CO + col] = acc[i][j][r];
     }
 }
 
-// g[co][ci][kh][kw] = sum over blocks of part[block][(kh*3+kw)*64 + ci][co]; threads run along co (contiguous reads)
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblk, int Cout, int Cin, float* __restrict__ g) {
+// g[co][ci][kh][kw] = sum over blocks of part[co / 64][block][(kh*3+kw)*CI + ci][co % 64]; threads run along co (contiguous reads)
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblk, int CI, int Cout, int Cin,
+                                                     float* __restrict__ g) {
   const int co = blockIdx.x * 32 + (threadIdx.x & 31);
   const int k = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (co >= Cout || k >= KT * 32) return;
-  const int tap = k / CH, ci = k - tap * CH;
+  if (co >= Cout || k >= 9 * CI) return;
+  const int tap = k / CI, ci = k - tap * CI;
   if (ci >= Cin) return;
-  const float* src = part + (long)k * CH + co;
-  const long sstride = (long)KT * 32 * CH;
+  const long slab = (long)9 * CI * CO;
+  const float* src = part + (long)(co / CO) * nblk * slab + (long)k * CO + (co % CO);
   float a = 0.f;
   int s = 0;
   for (; s + 4 <= nblk; s += 4) {
-    const float v0 = src[(long)s * sstride], v1 = src[(long)(s + 1) * sstride], v2 = src[(long)(s + 2) * sstride],
-                v3 = src[(long)(s + 3) * sstride];
+    const float v0 = src[(long)s * slab], v1 = src[(long)(s + 1) * slab], v2 = src[(long)(s + 2) * slab], v3 = src[(long)(s + 3) * slab];
     a += (v0 + v1) + (v2 + v3);
   }
-  for (; s < nblk; ++s) a += src[(long)s * sstride];
+  for (; s < nblk; ++s) a += src[(long)s * slab];
   g[((long)co * Cin + ci) * 9 + tap] = a;
 }
 
@@ -173,49 +184,57 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
                           long x_ld, long dz_ld, long scratch_elems) {
   static const bool off = getenv("DY_NO_WGRAD_V3") != nullptr;
   if (off) return false;
-  if (!(dtype == DY_BF16 && Cin_pad == 64 && Cout_pad == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1)) return false;
+  if (!(dtype == DY_BF16 && (Cin_pad == 64 || Cin_pad == 128) && Cout_pad % 64 == 0 && Cout_pad <= 128 && KH == 3 && KW == 3 && stride == 1 &&
+        pad == 1 && dil == 1))
+    return false;
   if ((x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
   const int PW = (Wi + 2 + 15) / 16 * 16;
-  if ((4 * (PW + 8) + 2 * PW) * wg3::PXB > 160 * 1024) return false;          // the six row buffers must fit LDS
-  // worth it when the pixel loop is long enough to amortise the 147 KB slab per block (64->64 at 40x40, B = 32 is not)
+  if (4 * (PW + 8) * Cin_pad * 2 + 2 * PW * wg3::ZPB > 160 * 1024) return false;       // the six row buffers must fit LDS
+  // worth it when the pixel loop is long enough to amortise the slab per block (64->64 at 40x40, B = 32 is not)
   static const long min_m = getenv("DY_WG3_MINM") ? atol(getenv("DY_WG3_MINM")) : 131072;
-  return (long)N * Hi * Wi >= min_m && scratch_elems >= 64L * wg3::KT * 32 * wg3::CH;
+  return (long)N * Hi * Wi >= min_m && scratch_elems >= (long)N * (Cout_pad / wg3::CO) * 9 * Cin_pad * wg3::CO;     // >= 1 block per image
 }
 
-int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, const void* dz, long dz_ld, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream) {
+int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
+                       int Cin, float* scratch, long scratch_elems, float* g_oihw, void* stream) {
   using namespace wg3;
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.dz = (const char*)dz; p.dz_ld = dz_ld;
   p.N = N; p.H = Hi; p.W = Wi;
   p.PW = (Wi + 2 + 15) / 16 * 16;
   p.XW = p.PW + 8;
+  p.co_stride = 0;
   p.part = scratch;
+  const int ny = Cout_pad / CO;
   // about 512 blocks, whole rows of one image each, and the slabs must fit the scratch buffer
-  const long slab = (long)KT * 32 * CH;
-  long target = 512;
-  if (target > scratch_elems / slab) target = scratch_elems / slab;
-  int nseg = (int)((target + N - 1) / N);
+  const long slab = (long)9 * Cin_pad * CO;
+  const long maxblk = scratch_elems / (slab * ny);
+  int nseg = (int)((512 / ny + N - 1) / N);
+  if ((long)N * nseg > maxblk) nseg = (int)(maxblk / N);
   if (nseg < 1) nseg = 1;
   if (nseg > Hi) nseg = Hi;
   p.rb = (Hi + nseg - 1) / nseg;
   p.nseg = (Hi + p.rb - 1) / p.rb;
   const int nblk = N * p.nseg;
-  DY_CHECK((long)nblk * slab <= scratch_elems, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems, (long)nblk * slab);
-  const int shmem = (4 * p.XW + 2 * p.PW) * PXB;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  DY_CHECK((long)nblk * ny * slab <= scratch_elems, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems,
+           (long)nblk * ny * slab);
+  const int shmem = 4 * p.XW * Cin_pad * 2 + 2 * p.PW * ZPB;
+  static int configured = 0;
+  const int bit = Cin_pad == 64 ? 1 : 2;
+  if (!(configured & bit)) {
+    const void* fn = Cin_pad == 64 ? reinterpret_cast<const void*>(&wgrad_kernel<64>) : reinterpret_cast<const void*>(&wgrad_kernel<128>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dy_set_error("wgrad_v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
     }
-    configured = true;
+    configured |= bit;
   }
   hipStream_t st = (hipStream_t)stream;
-  wgrad_kernel<<<nblk, NT, shmem, st>>>(p);
+  if (Cin_pad == 64) wgrad_kernel<64><<<dim3(nblk, ny), 384, shmem, st>>>(p);
+  else wgrad_kernel<128><<<dim3(nblk, ny), 768, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
-  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), KT * 32 / 8), 256, 0, st>>>(scratch, nblk, Cout, Cin, g_oihw);
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), 9 * Cin_pad / 8), 256, 0, st>>>(scratch, nblk, Cin_pad, Cout, Cin, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -66,6 +66,7 @@ PIPELINED = [(2, 64, 128, 40, 40, 3, 1, 1), (3, 128, 64, 32, 32, 3, 2, 1), (2, 6
              (4, 32, 64, 40, 40, 3, 1, 1), (4, 48, 96, 40, 40, 1, 1, 0), (4, 16, 72, 41, 40, 3, 2, 1),   # narrow source, wide destination
              (2, 128, 272, 48, 48, 3, 1, 1), (4, 64, 512, 33, 31, 3, 2, 1),   # >= 256 output channels: 256x256 wgrad / conv tiles
              (6, 60, 62, 150, 147, 3, 1, 1),   # band weight gradient (64-channel 3x3, long pixel loop), ragged width / channels
+             (24, 128, 128, 80, 72, 3, 1, 1), (24, 124, 64, 80, 72, 3, 1, 1), (24, 64, 128, 80, 72, 3, 1, 1),   # ... 128-channel variants
              (3, 256, 8, 37, 23, 1, 1, 0),     # thin 1x1 dgrad (ASFF weight_level convs)
              (2, 3, 16, 64, 64, 3, 2, 1), (2, 3, 64, 33, 47, 3, 2, 1)]   # stem: direct dot2 dgrad with planar dx
 
