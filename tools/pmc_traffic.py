@@ -17,13 +17,14 @@ from collections import defaultdict
 
 # GPU kernels behind each C-ABI entry whose kernels are uniquely named (bench.py's roofline classes)
 CLASSES = {
-    "dy_conv2d_wgrad": [r"wg2::wgrad_kernel", r"wg2::reduce_kernel", r"conv_wgrad_kernel", r"wgrad_reduce_kernel"],
+    "dy_conv2d_wgrad": [r"wg2::wgrad_kernel", r"wg2::reduce_kernel", r"wg3::wgrad_kernel", r"wg3::reduce_kernel", r"conv_wgrad_kernel",
+                        r"wgrad_reduce_kernel", r"dense_wgrad_kernel"],
     "dy_bn_act_bwd_reduce": [r"bn_act_bwd_reduce_kernel"],
     "dy_bn_act_bwd_apply": [r"bn_act_bwd_apply_kernel"],
     "dy_bn_act_fwd": [r"bn_act_fwd_kernel"],
     "dy_usm_bwd": [r"usm_bwd_kernel"],
 }
-MAIN = {"dy_conv2d_wgrad": [r"wg2::wgrad_kernel", r"conv_wgrad_kernel"]}      # one dispatch of these per C-ABI call
+MAIN = {"dy_conv2d_wgrad": [r"wg2::wgrad_kernel", r"wg3::wgrad_kernel", r"conv_wgrad_kernel", r"dense_wgrad_kernel"]}      # one dispatch of these per C-ABI call
 
 
 def load(path, counter):
