@@ -323,7 +323,10 @@ extern "C" int dy_debug_conv_stamps(unsigned long long* out) {
 // 100 such tiles and ran at 93 us against 56 us on the band kernel.
 bool dy_conv_prefers_256(const dy_conv_desc* d) {
   const long M = (long)d->N * d->Hd * d->Wd;
-  return d->Cd >= 256 && ((M + 255) / 256) * ((d->Cd + 255) / 256) >= 192;
+  const long tn = (d->Cd + 255) / 256;
+  // ... and when the channel tiles are not mostly padding (Cd = 320: 2 x 256 covers 1.6x the channels; 1x1 128->320 dgrad at 160x160
+  // runs 1031 us with 256-wide tiles, 830 us with 128-wide ones)
+  return d->Cd >= 256 && ((M + 255) / 256) * tn >= 192 && tn * 256 * 4 <= (long)d->Cd * 5;
 }
 
 bool dy_conv_v2_eligible(const dy_conv_desc* d) {

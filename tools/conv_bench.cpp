@@ -24,6 +24,8 @@ int main(int argc, char** argv) {
       {"s1 3x3 64->64 @160", B, 64, 64, 160, 160, 3, 1, 1},   {"s4 3x3 512->512 @20", B, 512, 512, 20, 20, 3, 1, 1},
       {"1x1 1280->512 @40", B, 1280, 512, 40, 40, 1, 1, 0},   {"1x1 256->256 @80", B, 256, 256, 80, 80, 1, 1, 0},
       {"3x3s2 256->512 @80", B, 256, 512, 80, 80, 3, 2, 1},   {"3x3s2 64->128 @320", B, 64, 128, 320, 320, 3, 2, 1},
+      {"1x1 320->128 @160", B, 320, 128, 160, 160, 1, 1, 0},  {"1x1 1024->256 @80", B, 1024, 256, 80, 80, 1, 1, 0},
+      {"1x1 2048->512 @40", B, 2048, 512, 40, 40, 1, 1, 0},
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
