@@ -65,10 +65,37 @@ class YOLO:
         v = DetectionValidator(get_cfg(ov))
         return v(self.model, loader)
 
-    def predict(self, source, **kw):
+    @torch.no_grad()
+    def predict(self, source, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, orig_shapes=None, **kw):
+        """reference engine/predictor.py stream_inference + DetectionPredictor.postprocess (models/yolo/detect/predict.py:12-38)
+        for an already letter-boxed batch: `source` is a uint8 [B,3,H,W] RGB tensor (or float in [0,1]); returns one `Results`
+        per image with boxes scaled back to `orig_shapes[i]` (default: the network input shape).  Image decoding / letter-boxing
+        (cv2) is outside the hot path."""
+        from ..utils import ops as uops
+        from .results import Results
+        from .validator import DetectionValidator
+        dev = next(self.model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("predict() needs the model on a GPU (there is no CPU path)")
+        was_training = self.model.training
         self.model.eval()
-        with torch.no_grad():
-            return self.model(source)
+        if source.dtype == torch.uint8:
+            v = DetectionValidator(get_cfg(dict(self.overrides)))
+            v.device = dev
+            img = v.preprocess(dict(img=source))["img"]
+        else:
+            img = source.to(dev).float()
+        preds = self.model(img)
+        dets = uops.non_max_suppression(preds, conf, iou, agnostic=agnostic_nms, max_det=max_det)
+        H, W = img.shape[2:]
+        out = []
+        for i, d in enumerate(dets):
+            shape = tuple(orig_shapes[i]) if orig_shapes is not None else (H, W)
+            d = d.clone()
+            uops.scale_boxes((H, W), d[:, :4], shape)          # also clips to the image, like predict.py:27
+            out.append(Results(shape, d, names=self.model.names))
+        self.model.train(was_training)
+        return out
 
     def save(self, path):
         torch.save(dict(state_dict=self.model.state_dict(), yaml=self.model.yaml, nc=self.model.yaml["nc"]), path)

@@ -194,3 +194,39 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert out["replicas_in_sync"] is True
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out          # cpu_baseline is an N=1 field
+
+
+def test_predict_results_vs_oracle_nms():
+    """YOLO.predict(): preprocess -> eval forward -> HIP NMS (predictor defaults: multi_label off) -> Results, against the oracle's
+    NMS + scale_boxes on the same raw predictions."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd import YOLO
+    from oracle import model as om
+    from oracle import val as oval
+    from parity_helpers import load_sd
+    dy.set_compute_dtype(torch.float32)
+    nc, S, B = 20, 128, 3
+    y = YOLO("yolov8n-lowlight.yaml")
+    shapes = {k: tuple(v.shape) for k, v in y.model.state_dict().items()}
+    sd = om.rng_fill(shapes, 21)
+    for k in sd:
+        if ".cv3." in k and k.endswith("2.bias"):
+            sd[k] = sd[k] + 3.0
+    load_sd(y.model, sd)
+    y.model.cuda()
+    g = np.random.default_rng(9)
+    img = torch.from_numpy((g.random((B, 3, S, S)) * 255).astype(np.uint8))
+    res = y.predict(img, conf=0.3, iou=0.6, orig_shapes=[(S, S), (96, 120), (S, S)])
+    with torch.no_grad():
+        raw = y.model.eval()((img.float() / 255).cuda())[0].float().cpu()
+    want = oval.non_max_suppression(raw, 0.3, 0.6, multi_label=False)
+    assert len(res) == B and sum(len(r) for r in res) > 10
+    for i, (r, w) in enumerate(zip(res, want)):
+        w = w.clone()
+        oval.scale_boxes((S, S), w[:, :4], r.orig_shape)
+        got = r.boxes.data.cpu()
+        assert got.shape == w.shape and torch.equal(got[:, 4:], w[:, 4:]), f"image {i}"         # same detections, same order
+        # torch divides by the gain as a multiplication by its reciprocal on the GPU: 1 ulp on rescaled boxes
+        assert torch.allclose(got[:, :4], w[:, :4], rtol=1e-6, atol=1e-4), f"image {i}"
+        assert r.boxes.xyxy.shape == (len(r), 4) and r.boxes.conf.shape == (len(r),) and r.boxes.cls.shape == (len(r),)
+        assert float(r.boxes.xyxyn.max()) <= 1.0 + 1e-6 if len(r) else True
