@@ -83,6 +83,7 @@ _SIGS = {
     "dy_adamw_step": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],
     "dy_ema_lerp": [vp, vp, f32, i64, vp],
     "dy_grad_accumulate": [vp, vp, i64, vp],
+    "dy_stream_fork": [vp, vp],
 }
 
 _lib = None

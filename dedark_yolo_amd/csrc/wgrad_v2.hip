@@ -231,28 +231,39 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
     }
 }
 
-// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % BP][co % BQ]; threads run along co (contiguous reads)
+// g[co][ci][kh][kw] = sum over splits of part[split][tile(k', co)][k' % BP][co % BQ].  Block = (32 consecutive co, one k'); eight
+// split-lanes walk the slabs with four loads in flight each and are added in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int splits, int tiles, int tiles_q, int BP, int BQ,
                                                      int Cout, int Cin, int Cin_pad, int KH, int KW, int Ktot,
                                                      float* __restrict__ g) {
-  const int co = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int k = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (co >= Cout || k >= Ktot) return;
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int co = blockIdx.x * 32 + cl;
+  const int k = blockIdx.y;
   const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
-  if (ci >= Cin) return;
-  const int tile = (k / BP) * tiles_q + co / BQ;
-  const float* src = part + ((long)tile * BP + (k % BP)) * BQ + (co % BQ);
-  const long sstride = (long)tiles * BP * BQ;
-  float a = 0.f;
-  int s = 0;
-  for (; s + 4 <= splits; s += 4) {
-    const float v0 = src[(long)s * sstride], v1 = src[(long)(s + 1) * sstride], v2 = src[(long)(s + 2) * sstride],
-                v3 = src[(long)(s + 3) * sstride];
-    a += (v0 + v1) + (v2 + v3);
+  if (ci >= Cin) return;                                     // block-uniform
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (co < Cout) {
+    const int tile = (k / BP) * tiles_q + co / BQ;
+    const float* src = part + ((long)tile * BP + (k % BP)) * BQ + (co % BQ);
+    const long sstride = (long)tiles * BP * BQ;
+    int s = sl;
+    for (; s + 24 < splits; s += 32) {
+      const float v0 = src[(long)s * sstride], v1 = src[(long)(s + 8) * sstride], v2 = src[(long)(s + 16) * sstride],
+                  v3 = src[(long)(s + 24) * sstride];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < splits; s += 8) a0 += src[(long)s * sstride];
   }
-  for (; s < splits; ++s) a += src[(long)s * sstride];
-  const int kh = tap / KW, kw = tap - kh * KW;
-  g[(((long)co * Cin + ci) * KH + kh) * KW + kw] = a;
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && co < Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += red[u][cl];
+    const int kh = tap / KW, kw = tap - kh * KW;
+    g[(((long)co * Cin + ci) * KH + kh) * KW + kw] = t;
+  }
 }
 
 }  // namespace wg2
@@ -307,7 +318,8 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.tiles_q = dy_cdiv(Cout_pad, BQ);
   const int tiles = tiles_p * p.tiles_q;
   // about two waves of blocks over the chip, at least 8 steps per block, and the slabs must fit the scratch buffer
-  const long target = (exp_mode == 1 || exp_mode == 2 || exp_mode == 4) ? 512 : 1024;
+  static const long env_target = getenv("DY_WG2_TARGET") ? atol(getenv("DY_WG2_TARGET")) : 0;
+  const long target = env_target > 0 ? env_target : (exp_mode == 1 || exp_mode == 2 || exp_mode == 4) ? 512 : 1024;
   long splits = (target + tiles - 1) / tiles;
   const long max_splits = (p.M + 8L * BKP - 1) / (8L * BKP);
   if (splits > max_splits) splits = max_splits;
@@ -326,7 +338,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   else if (exp_mode == 4) wgrad_kernel<256, 128, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
   else wgrad_kernel<128, 128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
-  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), dy_cdiv(p.Ktot, 8)), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, BQ, Cout, Cin, Cin_pad,
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), p.Ktot), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, BQ, Cout, Cin, Cin_pad,
                                                                             KH, KW, p.Ktot, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;

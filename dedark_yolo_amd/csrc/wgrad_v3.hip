@@ -161,21 +161,32 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
 // g[co][ci][kh][kw] = sum over blocks of part[co / 64][block][(kh*3+kw)*CI + ci][co % 64]; threads run along co (contiguous reads)
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblk, int CI, int Cout, int Cin,
                                                      float* __restrict__ g) {
-  const int co = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int k = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (co >= Cout || k >= 9 * CI) return;
+  // block = (32 consecutive co, one k); eight split-lanes walk the slabs, added in a fixed order
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int co = blockIdx.x * 32 + cl;
+  const int k = blockIdx.y;
   const int tap = k / CI, ci = k - tap * CI;
-  if (ci >= Cin) return;
+  if (ci >= Cin) return;                                     // block-uniform
   const long slab = (long)9 * CI * CO;
-  const float* src = part + (long)(co / CO) * nblk * slab + (long)k * CO + (co % CO);
-  float a = 0.f;
-  int s = 0;
-  for (; s + 4 <= nblk; s += 4) {
-    const float v0 = src[(long)s * slab], v1 = src[(long)(s + 1) * slab], v2 = src[(long)(s + 2) * slab], v3 = src[(long)(s + 3) * slab];
-    a += (v0 + v1) + (v2 + v3);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (co < Cout) {
+    const float* src = part + (long)(co / CO) * nblk * slab + (long)k * CO + (co % CO);
+    int s = sl;
+    for (; s + 24 < nblk; s += 32) {
+      const float v0 = src[(long)s * slab], v1 = src[(long)(s + 8) * slab], v2 = src[(long)(s + 16) * slab], v3 = src[(long)(s + 24) * slab];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < nblk; s += 8) a0 += src[(long)s * slab];
   }
-  for (; s < nblk; ++s) a += src[(long)s * slab];
-  g[((long)co * Cin + ci) * 9 + tap] = a;
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && co < Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += red[u][cl];
+    g[((long)co * Cin + ci) * 9 + tap] = t;
+  }
 }
 
 }  // namespace wg3
@@ -234,7 +245,7 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   if (Cin_pad == 64) wgrad_kernel<64><<<dim3(nblk, ny), 384, shmem, st>>>(p);
   else wgrad_kernel<128><<<dim3(nblk, ny), 768, shmem, st>>>(p);
   DY_LAUNCH_CHECK();
-  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), 9 * Cin_pad / 8), 256, 0, st>>>(scratch, nblk, Cin_pad, Cout, Cin, g_oihw);
+  reduce_kernel<<<dim3(dy_cdiv(Cout, 32), 9 * Cin_pad), 256, 0, st>>>(scratch, nblk, Cin_pad, Cout, Cin, g_oihw);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -140,7 +140,16 @@ class GradBuckets:
         b = self.owner[li]
         b["left"] -= 1
         if b["left"] == 0:
-            self.works.append(dist.all_reduce(self.flat.g[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True))
+            g = self.flat.g[b["start"]:b["end"]]
+            side = ops.wgrad_side_stream() if ops.wgrad_pending() else None
+            if side is None:
+                self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                # the bucket's weight gradients are on the side stream: issue the collective from there (after everything the
+                # compute stream has produced so far) instead of stalling the compute stream on a join
+                ops._side_wait_main()
+                with torch.cuda.stream(side):
+                    self.works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         for b in self.buckets:              # a layer that took no part in this backward (should not happen) is reduced here
@@ -189,6 +198,7 @@ class DetectionTrainer:
             for t in list(self.model.parameters()) + list(self.model.buffers()):       # K3: one broadcast of the start state
                 dist.broadcast(t.data, src=0)
         self.flat = FlatState(self.model, with_ema=True)
+        ops.enable_wgrad_stream(True)
         if self.world_size > 1:
             self.buckets = GradBuckets(self.flat, self.model)
         a = self.args
@@ -288,6 +298,7 @@ class DetectionTrainer:
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
         loss.backward()
+        ops.wgrad_join()
         if self.buckets is not None:
             self.buckets.finish()
         if lr is None:

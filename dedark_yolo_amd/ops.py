@@ -47,7 +47,14 @@ def round_up(c, m):
     return (c + m - 1) // m * m
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream (the raw accessor: torch.cuda.current_stream() costs ~8 us per call)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -301,7 +308,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         stats = arena.alloc(2 * cout_pad * _C.STATS_REPLICAS, dev)
         d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
                        False, dtype)
-        _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+        _C._prof is not None and _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         aff = torch.empty((4, cout_pad), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
@@ -310,7 +317,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
              cout_pad, stream())
         _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
         y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
-        _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
+        _C._prof is not None and _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
                     bytes=float(B * Ho * Wo * cout_pad * x.element_size() * (3 if residual is not None else 2)))
         call("dy_bn_act_fwd", ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), act, ptr(residual),
              ld_of(residual) if residual is not None else 0, ptr(y), ld_of(y), B * Ho * Wo, cout_pad, dt_id(dtype), stream())
@@ -328,7 +335,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         y = out if (out is not None and direct) else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         d = _conv_desc(x, wp, y, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, scale, shift, act, None, False,
                        dtype)
-        _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
+        _C._prof is not None and _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
         call("dy_conv2d_fwd", C.byref(d), stream())
         if not direct:                  # eval-time residual: y_out = y + residual
@@ -359,13 +366,86 @@ def _add_pgrad(tape, p, g):
 _wg_scratch = {}
 
 
-def wgrad_scratch(device, elems=32 << 20):
-    """Reusable f32 workspace for the split-pixel partial tiles of dy_conv2d_wgrad (128 MiB; stream-ordered reuse)."""
-    t = _wg_scratch.get(device)
+def wgrad_scratch(device, elems=32 << 20, tag=0):
+    """Reusable f32 workspace for the split-pixel partial tiles of dy_conv2d_wgrad (128 MiB; stream-ordered reuse, one per
+    launch stream: tag 0 = the compute stream, tag 1 = the weight-gradient side stream)."""
+    t = _wg_scratch.get((device, tag))
     if t is None or t.numel() < elems:
         t = torch.empty(elems, dtype=torch.float32, device=device)
-        _wg_scratch[device] = t
+        _wg_scratch[(device, tag)] = t
     return t
+
+
+# ---- weight gradients on a second HIP stream.  dgrad and wgrad of a conv both depend only on dz; the next layer's backward
+# depends only on the dgrad.  At the batch sizes of BASELINE configs[1] most kernels are launch-/latency-bound (20-50 us, a few
+# hundred blocks), so the wgrad + its split reduction are issued on a side stream where they fill the gaps of the
+# dz -> dgrad -> BN-backward chain.  Only used with direct gradient placement (the trainer's flat gradient buffer): gradients
+# handed back to autograd are accumulated on the compute stream and stay there.  The operands are kept alive until the join.
+class _WgradSide:
+    GROUP = 8                      # operands are released in groups of this many weight gradients (one event per group)
+
+    def __init__(self):
+        self.on = False
+        self.stream = None
+        self.raw = None            # hipStream_t of the side stream
+        self.cur = []              # operands of the group being filled
+        self.groups = []           # [(event recorded on the side stream after the group's last wgrad, operands)], issue order
+        self.free_events = []
+        self.cb_queued = False
+
+
+_wg_side = _WgradSide()
+
+
+def enable_wgrad_stream(on=True):
+    """Trainer switch (DY_WGRAD_STREAM=0 keeps everything on the compute stream)."""
+    _wg_side.on = bool(on) and os.environ.get("DY_WGRAD_STREAM", "1") != "0"
+
+
+def wgrad_side_stream(device=None):
+    s = _wg_side
+    if not s.on:
+        return None
+    if s.stream is None:
+        prio = int(os.environ.get("DY_WGRAD_PRIO", "0"))       # experiments: 1 = below the compute stream where HIP offers it
+        s.stream = torch.cuda.Stream(device=device, priority=prio)
+        s.raw = s.stream.cuda_stream
+    return s.stream
+
+
+def _side_wait_main(side=None):
+    """side stream waits for everything issued so far on the current (compute) stream."""
+    call("dy_stream_fork", stream(), _wg_side.raw)
+
+
+def _wg_track(x, dz):
+    """Keeps the operands of a side-stream wgrad alive; finished groups (oldest first) are released so that their memory
+    returns to the allocator during the backward pass instead of at the join."""
+    s = _wg_side
+    s.cur.append((x, dz))
+    if len(s.cur) < s.GROUP or torch.cuda.is_current_stream_capturing():
+        return
+    ev = s.free_events.pop() if s.free_events else torch.cuda.Event()
+    ev.record(s.stream)
+    s.groups.append((ev, s.cur))
+    s.cur = []
+    while s.groups and s.groups[0][0].query():
+        s.free_events.append(s.groups.pop(0)[0])
+
+
+def wgrad_pending():
+    return bool(_wg_side.cur or _wg_side.groups)
+
+
+def wgrad_join():
+    """The compute stream waits for the weight gradients issued so far; their operands may be freed afterwards."""
+    s = _wg_side
+    if s.cur or s.groups:
+        call("dy_stream_fork", s.raw, stream())
+        s.free_events.extend(g[0] for g in s.groups)
+        s.groups.clear()
+        s.cur = []
+    s.cb_queued = False
 
 
 def _grad_dst(p):
@@ -395,7 +475,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     if ctx.has_bn:
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
         sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)
-        _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
+        _C._prof is not None and _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
         call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
         dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
@@ -404,7 +484,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         if not direct:
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
-        _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
+        _C._prof is not None and _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
         call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
              ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
         if not direct:
@@ -439,11 +519,29 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     if ctx.owner.requires_grad:
         gd = _grad_dst(ctx.owner)
         gw = gd if gd is not None else torch.empty(ctx.weight.shape, dtype=torch.float32, device=dev)
-        scratch = wgrad_scratch(dev)
-        _C.set_meta(kind="conv_wgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+        side = wgrad_side_stream(dev) if gd is not None else None
+        st_w = st
+        if side is not None:
+            _side_wait_main()                          # dz (and, for a first step, x) are ready
+            if not _wg_side.cb_queued:                 # join at the end of this backward pass even without a trainer
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
+                    _wg_side.cb_queued = True
+                except RuntimeError:
+                    pass
+            st_w = side.cuda_stream
+        scratch = wgrad_scratch(dev, tag=0 if side is None else 1)
+        _C._prof is not None and _C.set_meta(kind="conv_wgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size() + Cout * KH * KW * Cin * 4))
-        call("dy_conv2d_wgrad", ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride,
-             ctx.pad, ctx.dil, Cout, Cin, ptr(scratch), scratch.numel(), ptr(gw), did, st)
+        wargs = (ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, Cout, Cin,
+                 ptr(scratch), scratch.numel(), ptr(gw), did)
+        if side is not None and _C._prof is not None:
+            with torch.cuda.stream(side):              # per-call timing: the events must sit on the launch stream
+                call("dy_conv2d_wgrad", *wargs, st_w)
+        else:
+            call("dy_conv2d_wgrad", *wargs, st_w)
+        if side is not None:
+            _wg_track(x, dz)
         if gd is None:
             _add_pgrad(tape, ctx.owner, gw.view(ctx.owner.shape))
     if not need_dx:
@@ -459,7 +557,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
                        None, False, dtype)
         d.dst_valid_channels = Cin
         d.dst_planar = dxp.data_ptr()
-        _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W} (planar)", dtype=str(dtype),
+        _C._prof is not None and _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W} (planar)", dtype=str(dtype),
                     flops=2.0 * pixels * Cout * KH * KW * Cin, bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size()))
         call("dy_conv2d_dgrad", C.byref(d), st)
         return dxp
@@ -473,7 +571,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
                    None, accumulate, dtype)
     d.dst_valid_channels = Cin
-    _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+    _C._prof is not None and _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                 bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)
     if dx_out is not None:

@@ -77,7 +77,7 @@ class _DetLossFn(torch.autograd.Function):
         B = maps[0].shape[0]
         dev = maps[0].device
         st = stream()
-        strides = [float(s) for s in crit.stride][:n_maps]
+        strides = crit.strides_as_floats()[:n_maps]
         a = assign(maps, strides, crit.nc, batch["batch_idx"], batch["cls"], batch["bboxes"], batch.get("n_max"))
         dm = ops.det_maps(maps, strides, crit.nc)
         acc = torch.zeros(4, dtype=torch.float64, device=dev)
@@ -129,6 +129,14 @@ class v8DetectionLoss:
         self.use_dfl = m.reg_max > 1
         self.assigner = TaskAlignedAssigner(topk=10, num_classes=self.nc, alpha=0.5, beta=6.0)
         self.last_assignment = None
+
+    def strides_as_floats(self):
+        """Detect.stride as host floats, read back once (a per-step float(tensor) is a device synchronisation)."""
+        key = (id(self.stride), self.stride._version)
+        if getattr(self, "_stride_key", None) != key:
+            self._stride_host = [float(s) for s in self.stride.detach().cpu()]
+            self._stride_key = key
+        return self._stride_host
 
     def __call__(self, preds, batch):
         feats = preds[1] if isinstance(preds, tuple) else preds

@@ -254,6 +254,10 @@ int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, f
 int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream);
 /* acc += g: gradient accumulation over `accumulate` batches (nbs / batch, U/engine/trainer.py:248,340-342) */
 int dy_grad_accumulate(float* acc, const float* g, int64_t n, void* stream);
+/* Stream plumbing of the backward pass (no counterpart in the single-stream reference): `to` waits for everything issued so far
+ * on `from` (hipEventRecord on an internal ring of timing-free events + hipStreamWaitEvent; no host synchronisation).  Used to
+ * run the weight gradients of a conv on a second HIP stream next to its dgrad -> BatchNorm-backward chain. */
+int dy_stream_fork(void* from, void* to);
 int dy_frontend_init(void); /* uploads the gaussian taps (call once per process, outside graph capture) */
 
 #ifdef __cplusplus

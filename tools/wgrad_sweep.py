@@ -7,7 +7,9 @@ from dedark_yolo_amd import ops
 from dedark_yolo_amd._C import call
 from dedark_yolo_amd.ops import ptr, stream, ld_of
 shapes = [(32, 64, 64, 40, 3, 1), (32, 32, 32, 80, 3, 1), (32, 64, 64, 80, 3, 1), (32, 16, 16, 160, 3, 1), (32, 3, 16, 640, 3, 2),
-          (32, 16, 32, 320, 3, 2), (32, 128, 128, 20, 3, 1), (32, 128, 64, 40, 3, 1), (32, 192, 128, 40, 1, 1), (32, 384, 256, 20, 1, 1)]
+          (32, 16, 32, 320, 3, 2), (32, 128, 128, 20, 3, 1), (32, 128, 64, 40, 3, 1), (32, 192, 128, 40, 1, 1), (32, 384, 256, 20, 1, 1),
+          (32, 64, 128, 80, 3, 2), (32, 128, 256, 40, 3, 2), (32, 256, 256, 20, 1, 1), (32, 128, 128, 40, 1, 1), (32, 64, 64, 80, 1, 1),
+          (32, 96, 64, 80, 1, 1), (32, 64, 20, 80, 1, 1), (32, 128, 64, 20, 3, 1), (32, 256, 64, 20, 3, 1)]
 dt = torch.bfloat16
 scratch = ops.wgrad_scratch(torch.device("cuda"))
 tot = 0.0
