@@ -110,7 +110,11 @@ def cpu_baseline(model_name, nc, S, seconds_budget=25.0):
 
 def kernel_profile(trainer, batches, steps=3):
     """Per-C-ABI-entry timing with events on the launch stream (torch's current stream) over `steps` extra steps."""
-    from dedark_yolo_amd import _C
+    from dedark_yolo_amd import _C, ops
+    # one stream while instrumenting: a kernel that shares the chip with the side streams' kernels (weight gradients, Detect
+    # levels) has an elapsed time that says nothing about its own efficiency
+    ops.enable_wgrad_stream(False)
+    ops.enable_branch_streams(False)
     _C._prof = []
     for i in range(steps):
         b = dict(batches[i % len(batches)])
@@ -118,6 +122,8 @@ def kernel_profile(trainer, batches, steps=3):
         trainer.train_step(b)
     torch.cuda.synchronize()
     rec, _C._prof = _C._prof, None
+    ops.enable_wgrad_stream(True)
+    ops.enable_branch_streams(True)
     agg = {}
     for name, e0, e1, meta in rec:
         key = name + ("/" + meta["dtype"].replace("torch.", "") if meta else "")
@@ -251,7 +257,9 @@ def main():
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
         roof.update(kernel=name, launches_per_step=a["n"] // psteps, avg_launch_us=round(avg_s * 1e6, 2),
                     share_of_kernel_time=round(a["ms"] / tot, 3), flop_per_byte=round(intensity, 1),
-                    algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]), traffic=pmc_traffic(args, name))
+                    algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]), traffic=pmc_traffic(args, name),
+                    streams="kernel durations taken on ONE stream (DY_WGRAD_STREAM=0 DY_BRANCH_STREAMS=0 equivalent); the timed "
+                            "region runs the weight gradients and the coarser Detect levels on side streams")
         out["roofline"] = roof
         out["kernel_time_breakdown_ms_per_step"] = {k: round(v["ms"] / psteps, 3) for k, v in top[:10]}
     if world > 1:

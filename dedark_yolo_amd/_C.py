@@ -113,12 +113,13 @@ def exported_symbols():
 
 _prof = None          # list of (name, start_event, end_event, meta) while bench.py's per-kernel timing is active
 _next_meta = None
+_UNTIMED = frozenset(["dy_stream_fork"])        # stream plumbing: events around it would time the wait, not a kernel
 
 
 def call(name, *args):
     global _next_meta
     L = lib()
-    if _prof is None:
+    if _prof is None or name in _UNTIMED:
         rc = getattr(L, name)(*args)
     else:
         import torch

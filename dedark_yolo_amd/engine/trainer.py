@@ -199,6 +199,7 @@ class DetectionTrainer:
                 dist.broadcast(t.data, src=0)
         self.flat = FlatState(self.model, with_ema=True)
         ops.enable_wgrad_stream(True)
+        ops.enable_branch_streams(True)
         if self.world_size > 1:
             self.buckets = GradBuckets(self.flat, self.model)
         a = self.args

@@ -452,27 +452,74 @@ class Detect(DyModule):
         self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
         self.dfl = DFL(self.reg_max)
 
+    def _level_fwd(self, tape, i, x):
+        B, _, H, W = x.shape
+        ve = ops.vec_elems(x.dtype)
+        nc_pad = ops.round_up(self.nc, ve)
+        buf = empty_nhwc(B, 4 * self.reg_max + nc_pad, H, W, x.dtype, x.device)
+        a, b, c = self.cv2[i]
+        t = b._fwd(tape, a._fwd(tape, x))
+        plain_conv_fwd(tape, c, t, out=buf[:, :4 * self.reg_max])
+        a, b, c = self.cv3[i]
+        t = b._fwd(tape, a._fwd(tape, x))
+        plain_conv_fwd(tape, c, t, out=buf[:, 4 * self.reg_max:4 * self.reg_max + nc_pad])
+        return buf[:, :self.no]
+
+    def _level_bwd(self, tape, i, g):
+        r = 4 * self.reg_max
+        nc_pad = ops.round_up(self.nc, ops.vec_elems(g.dtype))
+        if ld_of(g) < r + nc_pad:
+            raise RuntimeError("Detect: gradient map lacks channel padding")
+        gt = conv_backward(tape, g[:, r:r + self.nc])                      # cv3[i][2]
+        gt = self.cv3[i][1]._bwd(tape, gt)
+        dx = self.cv3[i][0]._bwd(tape, gt)
+        gt = conv_backward(tape, g[:, :r])                                 # cv2[i][2]
+        gt = self.cv2[i][1]._bwd(tape, gt)
+        return self.cv2[i][0]._bwd(tape, gt, dx_out=dx, accumulate=True)
+
+    def _run_levels(self, fn, tapes, args):
+        """fn(tapes[i], i, args[i]) for every pyramid level.  The levels are independent chains of small kernels (three convs
+        + BatchNorm each way), so when the trainer enabled branch streams the coarser levels run on side streams next to
+        level 0 on the compute stream: fork before, join after (everything later on the compute stream is ordered behind
+        them, which also covers the allocator's reuse of the operands)."""
+        n = len(args)
+        side = ops.branch_streams(n - 1, args[0].device) if (self.training and tapes[0] is not None) else None
+        out = [None] * n
+        if side is None:
+            for i in range(n):
+                out[i] = fn(tapes[i], i, args[i])
+            return out
+        main_raw = stream()
+        for i in range(1, n):                       # issue the side levels first: they run while level 0 is being issued
+            s = side[i - 1]
+            call("dy_stream_fork", main_raw, s.cuda_stream)
+            with torch.cuda.stream(s):
+                out[i] = fn(tapes[i], i, args[i])
+        out[0] = fn(tapes[0], 0, args[0])
+        for s in side:
+            call("dy_stream_fork", s.cuda_stream, main_raw)
+        return out
+
     def _fwd(self, tape, *xs):
-        maps = []
-        for i, x in enumerate(xs):
-            B, _, H, W = x.shape
-            ve = ops.vec_elems(x.dtype)
-            nc_pad = ops.round_up(self.nc, ve)
-            buf = empty_nhwc(B, 4 * self.reg_max + nc_pad, H, W, x.dtype, x.device)
-            a, b, c = self.cv2[i]
-            t = b._fwd(tape, a._fwd(tape, x))
-            plain_conv_fwd(tape, c, t, out=buf[:, :4 * self.reg_max])
-            a, b, c = self.cv3[i]
-            t = b._fwd(tape, a._fwd(tape, x))
-            plain_conv_fwd(tape, c, t, out=buf[:, 4 * self.reg_max:4 * self.reg_max + nc_pad])
-            maps.append(buf[:, :self.no])
+        subs = [Tape() if tape is not None else None for _ in xs]          # one tape per level: the levels are independent
+        maps = self._run_levels(self._level_fwd, subs, list(xs))
+        if tape is not None:
+            tape.push(subs)
         if self.training:
             return maps
-        m = ops.det_maps(maps, [float(s) for s in self.stride], self.nc)
+        m = ops.det_maps(maps, self.strides_as_floats(), self.nc)
         A = sum(t.shape[2] * t.shape[3] for t in maps)
         y = torch.empty((maps[0].shape[0], 4 + self.nc, A), dtype=torch.float32, device=maps[0].device)
         call("dy_detect_decode", C.byref(m), ptr(y), stream())
         return (y, *maps)
+
+    def strides_as_floats(self):
+        """self.stride as host floats, read back once (float(tensor) per call is a device synchronisation)."""
+        key = (id(self.stride), self.stride._version)
+        if self.__dict__.get("_stride_key") != key:
+            self.__dict__["_stride_host"] = [float(v) for v in self.stride.detach().cpu()]
+            self.__dict__["_stride_key"] = key
+        return self.__dict__["_stride_host"]
 
     def _wrap(self, out):
         if self.training:
@@ -482,19 +529,12 @@ class Detect(DyModule):
     def _bwd(self, tape, *dmaps, needs=None):
         if not self.training:
             raise RuntimeError("Detect: backward through the eval decode is not supported")
-        dxs = [None] * self.nl
-        r = 4 * self.reg_max
-        for i in reversed(range(self.nl)):
-            g = dmaps[i]
-            nc_pad = ops.round_up(self.nc, ops.vec_elems(g.dtype))
-            if ld_of(g) < r + nc_pad:
-                raise RuntimeError("Detect: gradient map lacks channel padding")
-            gt = conv_backward(tape, g[:, r:r + self.nc])                      # cv3[i][2]
-            gt = self.cv3[i][1]._bwd(tape, gt)
-            dx = self.cv3[i][0]._bwd(tape, gt)
-            gt = conv_backward(tape, g[:, :r])                                 # cv2[i][2]
-            gt = self.cv2[i][1]._bwd(tape, gt)
-            dxs[i] = self.cv2[i][0]._bwd(tape, gt, dx_out=dx, accumulate=True)
+        subs = tape.pop()
+        dxs = self._run_levels(self._level_bwd, subs, list(dmaps))
+        for t in subs:
+            assert not t.stack, "Detect: unbalanced level tape"
+            for p, g in t.pgrads.items():
+                ops._add_pgrad(tape, p, g)
         return dxs
 
     def bias_init(self):

@@ -448,6 +448,24 @@ def wgrad_join():
     s.cb_queued = False
 
 
+# ---- independent branches on their own streams (the three pyramid levels of the Detect head, forward and backward)
+_branch = {"on": False, "streams": []}
+
+
+def enable_branch_streams(on=True):
+    """Trainer switch (DY_BRANCH_STREAMS=0 keeps the branches on the compute stream)."""
+    _branch["on"] = bool(on) and os.environ.get("DY_BRANCH_STREAMS", "1") != "0"
+
+
+def branch_streams(n, device):
+    """n side streams for independent branches, or None when the switch is off."""
+    if not _branch["on"] or n <= 0:
+        return None
+    while len(_branch["streams"]) < n:
+        _branch["streams"].append(torch.cuda.Stream(device=device))
+    return _branch["streams"][:n]
+
+
 def _grad_dst(p):
     """p.grad storage when the trainer enabled direct gradient placement (kernels write there; autograd gets None)."""
     if p is not None and p.requires_grad and getattr(p, "_dy_direct", False) and p.grad is not None:
@@ -475,8 +493,9 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     if ctx.has_bn:
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
         sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)
+        pa, sa = aff.data_ptr(), 4 * cout_pad                               # rows of aff: scale, shift, mean, invstd
         _C._prof is not None and _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
-        call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
+        call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
              ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
         dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         gw_, gb_ = _grad_dst(bn.weight), _grad_dst(bn.bias)
@@ -485,7 +504,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
         _C._prof is not None and _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
-        call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
+        call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
              ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
         if not direct:
             _add_pgrad(tape, bn.weight, gw_)
