@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
   std::vector<Shape> shapes = {
       {"n P1 16@320", 32, 16, 320}, {"n P2 32@160", 32, 32, 160}, {"n P3 64@80", 32, 64, 80},   {"n P4 128@40", 32, 128, 40},
       {"n P5 256@20", 32, 256, 20}, {"L P1 64@320", 64, 64, 320}, {"L P2 128@160", 64, 128, 160}, {"L P3 256@80", 64, 256, 80},
-      {"L P4 512@40", 64, 512, 40}, {"L P5 512@20", 64, 512, 20},
+      {"L P4 512@40", 64, 512, 40}, {"L P5 512@20", 64, 512, 20}, {"n 64@40", 32, 64, 40}, {"n 128@20", 32, 128, 20}, {"n 64@20", 32, 64, 20},
+      {"n 32@80", 32, 32, 80},
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
