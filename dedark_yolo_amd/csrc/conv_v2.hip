@@ -378,6 +378,11 @@ int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
   // Infinity Cache every step, so the tile's flop-per-byte (128 vs 64 for 128 x 128) outweighs co-residency here.
   if (dy_conv_prefers_256(d) && exp_mode != 2) return DY_V2_GO(256, 2, 256);
   if (exp_mode == 3 && wide) return DY_V2_GO(128, 2, 512);      // experiment: 512 x 128 tile on 16 waves, exactly 160 KiB
+  // (few output pixels, wide: a 4-stage ring, 64-row tiles or 64x64 tiles were all slower or equal for the 100-block launches of
+  //  YOLOv8-n's 20x20 layers -- 128->128 3x3, B = 32: 29.1 us as is, 29.9 / 29.6 / 38.4 us)
+  // Launches with less than one block per CU (YOLOv8-n's 20x20 layers at B = 32: 100 blocks) were tried with a 3-stage ring,
+  // with 64-row tiles and with 128x64 tiles for Cd <= 64: all equal or slower (128->128 3x3: 29.2 us as is, 29.9 / 29.6 us;
+  // 256->64 3x3: 45.7 us as is, 50.1 / 65.5 us), so the shapes below stay.
   return wide ? DY_V2_GO(128, 2, 128) : DY_V2_GO(64, 2, 256);
 #undef DY_V2_GO
 }

@@ -27,6 +27,16 @@ int main(int argc, char** argv) {
       {"1x1 320->128 @160", B, 320, 128, 160, 160, 1, 1, 0},  {"1x1 1024->256 @80", B, 1024, 256, 80, 80, 1, 1, 0},
       {"1x1 2048->512 @40", B, 2048, 512, 40, 40, 1, 1, 0},
   };
+  if (argc > 3 && argv[3][0] == 'n') {       // YOLOv8-n layers with few output pixels (B = 32: 12,800 / 51,200 rows)
+    shapes = {
+        {"n 3x3 128->128 @20", B, 128, 128, 20, 20, 3, 1, 1}, {"n 3x3 256->64 @20", B, 256, 64, 20, 20, 3, 1, 1},
+        {"n 1x1 384->256 @20", B, 384, 256, 20, 20, 1, 1, 0}, {"n 1x1 256->256 @20", B, 256, 256, 20, 20, 1, 1, 0},
+        {"n 1x1 512->256 @20", B, 512, 256, 20, 20, 1, 1, 0}, {"n 3x3s2 128->256 @40", B, 128, 256, 40, 40, 3, 2, 1},
+        {"n 3x3 64->64 @40", B, 64, 64, 40, 40, 3, 1, 1},     {"n 1x1 192->128 @40", B, 192, 128, 40, 40, 1, 1, 0},
+        {"n 3x3s2 128->128 @40", B, 128, 128, 40, 40, 3, 2, 1}, {"n 3x3 128->64 @40", B, 128, 64, 40, 40, 3, 1, 1},
+        {"n 1x1 256->128 @20", B, 256, 128, 20, 20, 1, 1, 0},
+    };
+  }
   hipStream_t st;
   CK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
