@@ -764,6 +764,8 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
         q.stride = 1; q.pad = geo[0][2];
       }
     if (ok) {
+      // (running the four classes side by side on auxiliary streams was measured: 128->128 3x3 s2 at 40x40 58 -> 72 us, the
+      //  training step 10.4 -> 10.75 ms: the cross-stream waits cost more than the small launches gain)
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
         const dy_conv_desc* q = &c[i];
         int e;
