@@ -52,31 +52,50 @@ __device__ __noinline__ float adj_edge(const float* line, int pitch, int m, int 
   return c;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The 25-tap sums run on PAIRS of independent groups held as float2 (v_pk_add_f32 / v_pk_fma_f32: two results per VALU
+// instruction); every element still sees the same sequence k0*w[R], += k[d]*(w[R-d] + w[R+d]) as the scalar code, so the
+// results are bit-identical.  A pair shares nothing but the instruction stream: .x is group g, .y is group g2.
+__device__ inline void taps4x2(const f32x2 (&win)[28], f32x2 (&acc)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f32x2 a = c_taps[0] * win[e + R];
+#pragma unroll
+    for (int d = 1; d <= R; ++d) a += c_taps[d] * (win[e + R - d] + win[e + R + d]);
+    acc[e] = a;
+  }
+}
+
 // horizontal pass over all 64 staged rows; ADJ: add the adjoint's edge terms for the columns within R of the image border
 template <bool ADJ>
 __device__ inline void hpass(const float* __restrict__ tileT, float* __restrict__ tmp, int x0, int W) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int g = wave; g < TW / 4; g += NTH / 64) {
-    float win[28];
+  constexpr int NWV = NTH / 64;
+  static_assert((TW / 4) % (2 * NWV) == 0, "column groups pair up evenly");
+  for (int g = wave; g < TW / 4; g += 2 * NWV) {
+    const int g2 = g + NWV;
+    f32x2 win[28];
 #pragma unroll
-    for (int j = 0; j < 28; ++j) win[j] = tileT[(4 * g + j) * PT + lane];
-    float acc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = c_taps[0] * win[e + R];
-#pragma unroll
-      for (int d = 1; d <= R; ++d) a += c_taps[d] * (win[e + R - d] + win[e + R + d]);
-      acc[e] = a;
+    for (int j = 0; j < 28; ++j) {
+      win[j].x = tileT[(4 * g + j) * PT + lane];
+      win[j].y = tileT[(4 * g2 + j) * PT + lane];
     }
+    f32x2 acc[4];
+    taps4x2(win, acc);
     if (ADJ) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int m = x0 + 4 * g + e;                 // wave-uniform
-        if (m < W && (m <= R || m >= W - 1 - R)) acc[e] += adj_edge(tileT + lane, PT, m, x0, W);
+        const int m = x0 + 4 * g + e, m2 = x0 + 4 * g2 + e;      // wave-uniform
+        if (m < W && (m <= R || m >= W - 1 - R)) acc[e].x += adj_edge(tileT + lane, PT, m, x0, W);
+        if (m2 < W && (m2 <= R || m2 >= W - 1 - R)) acc[e].y += adj_edge(tileT + lane, PT, m2, x0, W);
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tmp[lane * PM + 4 * g + e] = acc[e];
+    for (int e = 0; e < 4; ++e) {
+      tmp[lane * PM + 4 * g + e] = acc[e].x;
+      tmp[lane * PM + 4 * g2 + e] = acc[e].y;
+    }
   }
 }
 
@@ -102,6 +121,75 @@ __device__ inline void vpass4(const float* __restrict__ tmp, int G, int lane, in
   }
 }
 
+// the same for two row groups at once (.x = G, .y = G2)
+template <bool ADJ>
+__device__ inline void vpass4x2(const float* __restrict__ tmp, int G, int G2, int lane, int y0, int H, f32x2 (&acc)[4]) {
+  f32x2 win[28];
+#pragma unroll
+  for (int j = 0; j < 28; ++j) {
+    win[j].x = tmp[(4 * G + j) * PM + lane];
+    win[j].y = tmp[(4 * G2 + j) * PM + lane];
+  }
+  taps4x2(win, acc);
+  if (ADJ) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = y0 + 4 * G + e, m2 = y0 + 4 * G2 + e;          // wave-uniform
+      if (m < H && (m <= R || m >= H - 1 - R)) acc[e].x += adj_edge(tmp + lane, PM, m, y0, H);
+      if (m2 < H && (m2 <= R || m2 >= H - 1 - R)) acc[e].y += adj_edge(tmp + lane, PM, m2, y0, H);
+    }
+  }
+}
+
+// Row groups of the vertical pass: wave w owns w and w + 4 (a pair) and, for w < NG - 8, w + 8 (alone).
+template <bool ADJ>
+__device__ inline void vpass_all(const float* __restrict__ tmp, int wave, int lane, int y0, int H, float (&a)[3][4]) {
+  constexpr int NG = TH / 4;
+  static_assert(NG > 7 && NG <= 12, "two full groups per wave, at most one more");
+  f32x2 p[4];
+  vpass4x2<ADJ>(tmp, wave, wave + 4, lane, y0, H, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[0][e] = p[e].x;
+    a[1][e] = p[e].y;
+    a[2][e] = 0.f;
+  }
+  if (wave + 8 < NG) vpass4<ADJ>(tmp, wave + 8, lane, y0, H, a[2]);
+}
+
+// Stages the (TH+24) x (TW+24) reflected tile of one PLANAR plane (H x W, f32 or the compute dtype) into tileT (transposed):
+// 4 columns per step with one 16- / 8-byte load where the chunk lies inside the image (x0 - R is a multiple of 4), element-wise
+// reflection on the border chunks.  (The first version computed a div / mod and two reflections per ELEMENT: more VALU work
+// than the two blur passes together.)
+template <typename S>
+__device__ inline void stage_planar(const S* __restrict__ pl, float* __restrict__ tileT, int y0, int x0, int H, int W) {
+  constexpr int CH = LW / 4;
+  static_assert(LW % 4 == 0 && R % 4 == 0 && TW % 4 == 0, "4-column chunks");
+  const bool vec_ok = (W & 3) == 0;
+  for (int i = threadIdx.x; i < LH * CH; i += NTH) {
+    const int r = i / CH, cq = i - r * CH;
+    const int yy = reflect(y0 + r - R, H);
+    const int gx = x0 - R + 4 * cq;
+    const S* row = pl + (long)yy * W;
+    float v[4];
+    if (vec_ok && gx >= 0 && gx + 3 < W) {
+      if constexpr (sizeof(S) == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(row + gx);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        const uint2 t = *reinterpret_cast<const uint2*>(row + gx);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = DT<S>::ld(row + reflect(gx + j, W));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tileT[(4 * cq + j) * PT + r] = v[j];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NTH, 4) void usm_fwd_kernel(const float* __restrict__ s4, const float* __restrict__ params,
                                                        float* __restrict__ out, T* __restrict__ out8, float* __restrict__ hp, int B,
@@ -117,24 +205,21 @@ __global__ __launch_bounds__(NTH, 4) void usm_fwd_kernel(const float* __restrict
   for (int c = 0; c < 3; ++c) {
     const float* pl = s4 + ((long)b * 3 + c) * H * W;
     __syncthreads();                             // previous channel's vpass still reads tileT / tmp
-    for (int i = tid; i < LH * LW; i += NTH) {
-      const int r = i / LW, q = i - r * LW;
-      tileT[q * PT + r] = pl[(long)reflect(y0 + r - R, H) * W + reflect(x0 + q - R, W)];
-    }
+    stage_planar<float>(pl, tileT, y0, x0, H, W);
     __syncthreads();
     hpass<false>(tileT, tmp, x0, W);
     __syncthreads();
+    float a[3][4];
+    vpass_all<false>(tmp, wave, lane, y0, H, a);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int G = wave + 4 * k;
       if (G < NG) {
-        float a[4];
-        vpass4<false>(tmp, G, lane, y0, H, a);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int t = 4 * G + e;
           const float v = tileT[(lane + R) * PT + t + R];
-          const float hi = v - a[e];
+          const float hi = v - a[k][e];
           const float o = hi * lam + v;
           res[c][k][e] = o;
           const int yy = y0 + t, xx = x0 + lane;
@@ -171,8 +256,10 @@ __global__ __launch_bounds__(NTH, 4) void usm_fwd_kernel(const float* __restrict
   }
 }
 
+// (3 blocks per CU: the pair windows plus the adjoint's edge calls need ~150 VGPRs; at the 128 of 4 blocks per CU the kernel
+//  spilled 15 VGPRs + 64 SGPRs and went from 394 to 493 us)
 template <typename T>
-__global__ __launch_bounds__(NTH, 4) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
+__global__ __launch_bounds__(NTH, 3) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
                                                        const float* __restrict__ hp, const float* __restrict__ params,
                                                        float* __restrict__ ds4, float* dparams, int B, int H, int W) {
   __shared__ float tileT[LW * PT];
@@ -187,32 +274,34 @@ __global__ __launch_bounds__(NTH, 4) void usm_bwd_kernel(const float* __restrict
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
     // the gradient of one channel, reflected like the forward input (the neighbouring blocks' copies come from L2)
-    for (int i = tid; i < LH * LW; i += NTH) {
-      const int r = i / LW, q = i - r * LW;
-      const int yy = reflect(y0 + r - R, H), xx = reflect(x0 + q - R, W);
-      float v;
-      if (dout) {
-        v = dout[(((long)b * 3 + c) * H + yy) * W + xx];
-      } else if (ld8 == 0) {                                   // planar [B,3,H,W] in the compute dtype (direct stem dgrad)
-        v = DT<T>::ld(dout8 + (((long)b * 3 + c) * H + yy) * W + xx);
-      } else if (ld8 == VE) {
-        float t[VE];
-        ldvec<T>(dout8 + (((long)b * H + yy) * W + xx) * VE, t);
-        v = c == 0 ? t[0] : (c == 1 ? t[1] : t[2]);
-      } else {
-        v = DT<T>::ld(dout8 + (((long)b * H + yy) * W + xx) * ld8 + c);
+    if (dout) {
+      stage_planar<float>(dout + ((long)b * 3 + c) * H * W, tileT, y0, x0, H, W);
+    } else if (ld8 == 0) {                                     // planar [B,3,H,W] in the compute dtype (direct stem dgrad)
+      stage_planar<T>(dout8 + ((long)b * 3 + c) * H * W, tileT, y0, x0, H, W);
+    } else {
+      for (int i = tid; i < LH * LW; i += NTH) {
+        const int r = i / LW, q = i - r * LW;
+        const int yy = reflect(y0 + r - R, H), xx = reflect(x0 + q - R, W);
+        float v;
+        if (ld8 == VE) {
+          float t[VE];
+          ldvec<T>(dout8 + (((long)b * H + yy) * W + xx) * VE, t);
+          v = c == 0 ? t[0] : (c == 1 ? t[1] : t[2]);
+        } else {
+          v = DT<T>::ld(dout8 + (((long)b * H + yy) * W + xx) * ld8 + c);
+        }
+        tileT[q * PT + r] = v;
       }
-      tileT[q * PT + r] = v;
     }
     __syncthreads();
     hpass<true>(tileT, tmp, x0, W);
     __syncthreads();
+    float a[3][4];
+    vpass_all<true>(tmp, wave, lane, y0, H, a);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int G = wave + 4 * k;
       if (G < NG) {
-        float a[4];
-        vpass4<true>(tmp, G, lane, y0, H, a);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int t = 4 * G + e;
@@ -220,7 +309,7 @@ __global__ __launch_bounds__(NTH, 4) void usm_bwd_kernel(const float* __restrict
           if (yy < H && xx < W) {
             const float g = tileT[(lane + R) * PT + t + R];
             const long idx = (((long)b * 3 + c) * H + yy) * W + xx;
-            ds4[idx] = g * (1.f + lam) - lam * a[e];
+            ds4[idx] = g * (1.f + lam) - lam * a[k][e];
             dl += g * hp[idx];
           }
         }

@@ -35,6 +35,9 @@ def main():
         tr.args.dark_param = b["gamma"]
         tr.train_step(b)
     torch.cuda.synchronize()
+    from dedark_yolo_amd import ops
+    ops.enable_wgrad_stream(False)          # one stream: per-call durations are only meaningful without co-running kernels
+    ops.enable_branch_streams(False)
     _C._prof = []
     for i in range(a.steps):
         b = dict(batches[i % 2])
