@@ -19,6 +19,7 @@
 // pipelined wide-channel bf16 kernel (conv_v2.hip)
 bool dy_conv_v2_eligible(const dy_conv_desc* d);
 int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
+int dy_conv_v2_launch_classes(const dy_conv_desc* classes, int ncls, void* stream);
 // band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
 int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
@@ -71,6 +72,8 @@ struct ConvP {
   long dst_row, dst_img;          // destination row / image strides in elements (dst_row == 0: dense, offset = m * dst_ld)
   int kh0, khs, kw0, kws, KWf;    // window tap (th, tw) -> weight tap (kh0 + khs*th, kw0 + kws*tw) of a KWf-wide pack
   long w_row;                     // elements per output-channel row of the weight pack (KHf*KWf*Cs)
+  int ncls;                       // > 1: parity classes of a stride-2 data gradient in one launch
+  DyParityCls cls[4];
 };
 
 template <typename PP>
@@ -130,7 +133,8 @@ __device__ inline void mma_step(const char* As, const char* Bs, int a_row0, int 
 // The 128x32 tile (narrow n-scale layers) is latency-bound: six co-resident blocks per CU (78-80 VGPRs, 23 KB LDS each) instead
 // of four cut the narrow forward / dgrad layers by 0.19 ms per C2 step.
 template <typename T, int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kernel(const ConvP pk) {
+  ConvP p = pk;
   constexpr int VE = DT<T>::VE;
   constexpr int BK = 8 * VE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -142,7 +146,16 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  int bid = xcd_remap(blockIdx.x, p.nblk);
+  if (pk.ncls > 1) {                       // several problems in one launch: this block's class replaces the launch-wide geometry
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < pk.ncls && bid >= pk.cls[i].blk0) c = i;
+    p.dst = pk.cls[c].dst; p.M = pk.cls[c].M; p.Hd = pk.cls[c].Hd; p.Wd = pk.cls[c].Wd; p.KH = pk.cls[c].KH; p.KW = pk.cls[c].KW;
+    p.pad = pk.cls[c].pad; p.kh0 = pk.cls[c].kh0; p.kw0 = pk.cls[c].kw0; p.Ktot = pk.cls[c].Ktot;
+    bid -= pk.cls[c].blk0;
+  }
   const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -652,8 +665,18 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 }
 
 template <typename T, int MODE>
-int launch_conv(const dy_conv_desc* d, hipStream_t st) {
+int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* classes = nullptr, int ncls = 0) {
   ConvP p;
+  p.ncls = 0;
+  if (ncls > 1) {
+    p.ncls = ncls;
+    for (int c = 0; c < ncls; ++c) {
+      const dy_conv_desc& q = classes[c];
+      DyParityCls& k = p.cls[c];
+      k.dst = (char*)q.dst; k.M = (long)q.N * q.Hd * q.Wd; k.Hd = q.Hd; k.Wd = q.Wd; k.KH = q.KH; k.KW = q.KW; k.pad = q.pad;
+      k.kh0 = q.kh0; k.kw0 = q.kw0; k.Ktot = q.KH * q.KW * q.Cs; k.blk0 = 0; k._r = 0;
+    }
+  }
   p.src = (const char*)d->src; p.src_ld = d->src_ld; p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
   p.w = (const char*)d->w; p.dst = (char*)d->dst; p.dst_ld = d->dst_ld; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -673,17 +696,26 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st) {
   }
   constexpr int BM = 128;
   const int tiles_m = dy_cdiv(p.M, BM);
-  if (d->Cd <= 32) {
-    p.tiles_n = dy_cdiv(d->Cd, 32);
+  auto blocks = [&](int bn) {                 // tiles_n / nblk (+ the block ranges of the classes)
+    p.tiles_n = dy_cdiv(d->Cd, bn);
     p.nblk = tiles_m * p.tiles_n;
+    if (p.ncls > 1) {
+      long acc = 0;
+      for (int c = 0; c < p.ncls; ++c) {
+        p.cls[c].blk0 = (int)acc;
+        acc += dy_cdiv(p.cls[c].M, BM) * p.tiles_n;
+      }
+      p.nblk = (int)acc;
+    }
+  };
+  if (d->Cd <= 32) {
+    blocks(32);
     conv_igemm_kernel<T, BM, 32, 4, 1, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
   } else if (d->Cd <= 64) {
-    p.tiles_n = dy_cdiv(d->Cd, 64);
-    p.nblk = tiles_m * p.tiles_n;
+    blocks(64);
     conv_igemm_kernel<T, BM, 64, 2, 2, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
   } else {
-    p.tiles_n = dy_cdiv(d->Cd, 128);
-    p.nblk = tiles_m * p.tiles_n;
+    blocks(128);
     conv_igemm_kernel<T, BM, 128, 2, 2, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
   }
   DY_LAUNCH_CHECK();
@@ -766,6 +798,23 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
     if (ok) {
       // (running the four classes side by side on auxiliary streams was measured: 128->128 3x3 s2 at 40x40 58 -> 72 us, the
       //  training step 10.4 -> 10.75 ms: the cross-stream waits cost more than the small launches gain)
+      // All classes in ONE launch (blocks ordered heaviest class first): four back-to-back launches of 1-, 2-, 2- and 4-tap
+      // problems each paid their own launch floor and tail.  DY_PARITY_MULTI=0 keeps the separate launches.
+      static const bool multi = !(getenv("DY_PARITY_MULTI") && atoi(getenv("DY_PARITY_MULTI")) == 0);
+      if (multi && nc > 1) {
+        dy_conv_desc r[4];
+        bool all_v2 = true, none_v2 = true;
+        for (int i = 0; i < nc; ++i) {
+          r[i] = c[nc - 1 - i];
+          const bool e2 = dy_conv_v2_eligible(&r[i]);
+          all_v2 = all_v2 && e2;
+          none_v2 = none_v2 && !e2;
+        }
+        if (all_v2) return dy_conv_v2_launch_classes(r, nc, stream);
+        if (none_v2)
+          return d->dtype == DY_F32 ? launch_conv<float, 0>(&r[0], (hipStream_t)stream, r, nc)
+                                    : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc);
+      }
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
         const dy_conv_desc* q = &c[i];
         int e;

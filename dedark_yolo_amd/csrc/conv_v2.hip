@@ -55,6 +55,8 @@ struct P {
   long dst_row, dst_img;          // destination row / image strides in elements (dst_row == 0: dense)
   int kh0, khs, kw0, kws, KWf;    // window tap -> weight tap mapping (tap subsets of a parity-split data gradient)
   long w_row;                     // elements per output-channel row of the weight pack
+  int ncls;                       // > 1: parity classes of a stride-2 data gradient in one launch
+  DyParityCls cls[4];
 };
 
 __device__ inline long dst_offset(const P& p, long m) {
@@ -76,7 +78,8 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 // lane derives (tap, channel) of ITS 16-byte chunk; K = KH*KW*Cs is padded to the step with zero-page loads.
 // BM x BN block tile on (BM/64) x 2 waves (wave tile 64 x BN/2); NSTAGE-deep LDS ring.
 template <int BM, int BN, int MODE, bool SMALLC, int NSTAGE>
-__global__ __launch_bounds__(BM * 2) void conv_kernel(P p) {
+__global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
+  P p = pk;
   constexpr int WN = 2, WM = BM / 64, NW = WM * WN, NT = 64 * NW;
   constexpr int TM = BM / WM / 32;          // 2
   constexpr int TN = BN / WN / 32;          // 2 (BN=128) or 1 (BN=64)
@@ -88,7 +91,16 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stamp(p.ablate, 0);
   const int wm = wave >> 1, wn = wave & 1;
-  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  int bid = xcd_remap(blockIdx.x, p.nblk);
+  if (pk.ncls > 1) {                       // several problems in one launch: this block's class replaces the launch-wide geometry
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < pk.ncls && bid >= pk.cls[i].blk0) c = i;
+    p.dst = pk.cls[c].dst; p.M = pk.cls[c].M; p.Hd = pk.cls[c].Hd; p.Wd = pk.cls[c].Wd; p.KH = pk.cls[c].KH; p.KW = pk.cls[c].KW;
+    p.pad = pk.cls[c].pad; p.kh0 = pk.cls[c].kh0; p.kw0 = pk.cls[c].kw0; p.Ktot = pk.cls[c].Ktot;
+    bid -= pk.cls[c].blk0;
+  }
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -307,6 +319,14 @@ int launch(P& p, hipStream_t st) {
   }
   p.tiles_n = dy_cdiv(p.Cd, BN);
   p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
+  if (p.ncls > 1) {
+    long acc = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+      p.cls[c].blk0 = (int)acc;
+      acc += dy_cdiv(p.cls[c].M, BM) * p.tiles_n;
+    }
+    p.nblk = (int)acc;
+  }
   conv_kernel<BM, BN, MODE, SMALLC, NSTAGE><<<p.nblk, BM * 2, SHMEM, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
@@ -342,8 +362,29 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d) {
   return d->Cs % 8 == 0 && d->Cd % 8 == 0 && (d->Cd >= 64 || (force && d->Cd >= 8));
 }
 
-int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) {
+static int v2_launch_impl(const dy_conv_desc* d, int mode, const dy_conv_desc* classes, int ncls, void* stream);
+
+int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream) { return v2_launch_impl(d, mode, nullptr, 0, stream); }
+
+// `classes[0..ncls)`: forward-style problems that differ only in destination offset, grid extent, tap subset and pad (the parity
+// classes of a stride-2 data gradient); one launch, blocks ordered class by class.
+int dy_conv_v2_launch_classes(const dy_conv_desc* classes, int ncls, void* stream) {
+  return v2_launch_impl(&classes[0], 0, classes, ncls, stream);
+}
+
+static int v2_launch_impl(const dy_conv_desc* d, int mode, const dy_conv_desc* classes, int ncls, void* stream) {
   v2::P p;
+  p.ncls = 0;
+  if (ncls > 1) {
+    DY_CHECK(ncls <= 4, "conv_v2: at most 4 classes");
+    p.ncls = ncls;
+    for (int c = 0; c < ncls; ++c) {
+      const dy_conv_desc& q = classes[c];
+      DyParityCls& k = p.cls[c];
+      k.dst = (char*)q.dst; k.M = (long)q.N * q.Hd * q.Wd; k.Hd = q.Hd; k.Wd = q.Wd; k.KH = q.KH; k.KW = q.KW; k.pad = q.pad;
+      k.kh0 = q.kh0; k.kw0 = q.kw0; k.Ktot = q.KH * q.KW * q.Cs; k.blk0 = 0; k._r = 0;
+    }
+  }
   p.src = (const char*)d->src; p.src_ld = d->src_ld; p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
   p.w = (const char*)d->w; p.dst = (char*)d->dst; p.dst_ld = d->dst_ld; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;

@@ -52,6 +52,14 @@ __device__ inline bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// One parity class of a stride-2 data gradient (conv.hip: dy_conv2d_dgrad): the conv kernels take up to four of them in one
+// launch, block ranges [blk0, next blk0) select the class and the fields below replace the launch-wide ones.
+struct DyParityCls {
+  char* dst;
+  long M;
+  int Hd, Wd, KH, KW, pad, kh0, kw0, Ktot, blk0, _r;
+};
+
 template <typename T> struct DT;
 template <> struct DT<float> {
   static constexpr int id = DY_F32;
