@@ -358,6 +358,142 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
   }
 }
 
+// ---- thin layers: Cs in {16, 32, 48}, Cd <= 32 (bf16) ----------------------------------------------------------------------
+// With so few channels a K-step of the tiled kernel above is one or two taps and the block spends its life in barriers and load
+// latency (16->16 3x3 at 160x160, B = 32: 45 us for 52 MB of operands = 1.2 TB/s).  Here NOTHING of the activation goes through
+// LDS: the A fragment of a 32x32x16 MFMA is, per lane, 8 consecutive channels of one pixel -- exactly one 16-byte load from the
+// NHWC tensor (lane&31 = pixel of the tile, lane>>5 = channel half of the 16-channel slab), shifted per tap; the 9 taps re-read
+// the same lines from L1 / L2.  The weights (<= 27 KB) are staged once per block in LDS in fragment order.  No barriers in the
+// main loop; a wave keeps 2 pixel tiles x 3 taps of loads in flight.  MODE as above (MODE 1 only with stride 1).
+constexpr int THIN_BM = 256;                 // 4 waves x 2 tiles x 32 pixels
+constexpr int THIN_MAX_SLABS = 27;           // 9 taps x 48 channels
+
+template <int CS16, int MODE>
+__global__ __launch_bounds__(NTHREADS, (CS16 == 3 ? 3 : 4)) void conv_thin_kernel(const ConvP pk) {
+  ConvP p = pk;
+  __shared__ __attribute__((aligned(16))) char smem[THIN_MAX_SLABS * 1024];
+  static_assert(dy_epi::image_bytes<THIN_BM, 32>() <= THIN_MAX_SLABS * 1024, "epilogue image reuses the weight buffer");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, p.nblk);
+  if (pk.ncls > 1) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < pk.ncls && bid >= pk.cls[i].blk0) c = i;
+    p.dst = pk.cls[c].dst; p.M = pk.cls[c].M; p.Hd = pk.cls[c].Hd; p.Wd = pk.cls[c].Wd; p.KH = pk.cls[c].KH; p.KW = pk.cls[c].KW;
+    p.pad = pk.cls[c].pad; p.kh0 = pk.cls[c].kh0; p.kw0 = pk.cls[c].kw0; p.Ktot = pk.cls[c].Ktot;
+    bid -= pk.cls[c].blk0;
+  }
+  const long m0 = (long)bid * THIN_BM;
+  const int ntaps = p.KH * p.KW;
+
+  // ---- weights -> LDS in fragment order: slab s = tap * CS16 + c16, lane slot l = (n = l & 31, channel half = l >> 5)
+  for (int idx = tid; idx < ntaps * CS16 * 64; idx += NTHREADS) {
+    const int sl = idx >> 6, l = idx & 63;
+    const int tap = sl / CS16, c16 = sl - tap * CS16;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int n = l & 31, half = l >> 5;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < p.Cd) {
+      const long wk = (long)((p.kh0 + p.khs * kh) * p.KWf + p.kw0 + p.kws * kw) * p.Cs + c16 * 16 + half * 8;
+      v = *reinterpret_cast<const u32x4*>(p.w + ((long)n * p.w_row + wk) * 2);
+    }
+    *reinterpret_cast<u32x4*>(smem + (long)idx * 16) = v;
+  }
+  __syncthreads();
+
+  // ---- this lane's pixel of each of the wave's two tiles
+  const int row = lane & 31, half = lane >> 5;
+  const long HWd = (long)p.Hd * p.Wd;
+  const char* a_base[2];
+  int a_h[2], a_w[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long m = m0 + wave * 64 + i * 32 + row;
+    a_ok[i] = m < p.M;
+    const long mm = a_ok[i] ? m : 0;
+    const int img = (int)(mm / HWd);
+    const int rem = (int)(mm - (long)img * HWd);
+    const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    a_base[i] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + half * 8) * 2;
+    if (MODE == 0) {
+      a_h[i] = oh * p.stride - p.pad;
+      a_w[i] = ow * p.stride - p.pad;
+    } else {
+      a_h[i] = oh + p.pad;
+      a_w[i] = ow + p.pad;
+    }
+  }
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+  for (int kh = 0; kh < p.KH; ++kh) {
+    u32x4 af[3][2][CS16];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sh = MODE == 0 ? a_h[i] + kh : a_h[i] - kh;
+        const int sw = MODE == 0 ? a_w[i] + kw : a_w[i] - kw;
+        const bool ok = kw < p.KW && a_ok[i] && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws;
+        const char* src = a_base[i] + ((long)sh * p.Ws + sw) * p.src_ld * 2;
+#pragma unroll
+        for (int c = 0; c < CS16; ++c) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (ok) v = *reinterpret_cast<const u32x4*>(src + c * 32);
+          af[kw][i][c] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      if (kw < p.KW) {
+        const char* bsl = smem + ((long)((kh * p.KW + kw) * CS16) * 64 + lane) * 16;
+#pragma unroll
+        for (int c = 0; c < CS16; ++c) {
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(bsl + c * 1024);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kw][i][c]), __builtin_bit_cast(bf16x8, bf),
+                                                               acc[i][0], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (conv_epilogue.h; its leading barrier also ends the reads of the weight image)
+  float csum[1], csq[1];
+  dy_epi::store_tile<THIN_BM, 32, 4, 1, 2, 1>(smem, acc, wave, 0, lane, wave, m0, 0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
+                                             reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][32][2]
+    const float s1 = csum[0] + __shfl_xor(csum[0], 32, 64);
+    const float s2 = csq[0] + __shfl_xor(csq[0], 32, 64);
+    if (half == 0) {
+      red[(wave * 32 + row) * 2] = s1;
+      red[(wave * 32 + row) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < 32 && tid < p.Cd) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[(w * 32 + tid) * 2];
+        t2 += red[(w * 32 + tid) * 2 + 1];
+      }
+      double* st = p.stats + (long)(bid % DY_STATS_REPLICAS) * 2 * p.Cd;
+      atomic_add_f64(st + tid, (double)t1);
+      atomic_add_f64(st + p.Cd + tid, (double)t2);
+    }
+  }
+}
+
 // ---- weight gradient ------------------------------------------------------------------------------------------------
 // dW[co][k] += sum_m dz[m][co] * X[m][k],  k = (kh,kw,ci).  GEMM rows = co, cols = k, reduction over pixels m.
 // Both operands are pixel-major in HBM, MFMA wants the reduction index contiguous per lane: each thread loads a
@@ -664,9 +800,7 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
   }
 }
 
-template <typename T, int MODE>
-int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* classes = nullptr, int ncls = 0) {
-  ConvP p;
+void fill_convp(ConvP& p, const dy_conv_desc* d, const dy_conv_desc* classes, int ncls) {
   p.ncls = 0;
   if (ncls > 1) {
     p.ncls = ncls;
@@ -694,6 +828,12 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* class
     p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = d->KW;
     p.w_row = p.Ktot;
   }
+}
+
+template <typename T, int MODE>
+int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* classes = nullptr, int ncls = 0) {
+  ConvP p;
+  fill_convp(p, d, classes, ncls);
   constexpr int BM = 128;
   const int tiles_m = dy_cdiv(p.M, BM);
   auto blocks = [&](int bn) {                 // tiles_n / nblk (+ the block ranges of the classes)
@@ -718,6 +858,44 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* class
     blocks(128);
     conv_igemm_kernel<T, BM, 128, 2, 2, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
   }
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+// thin-layer kernel: bf16, 16 / 32 / 48 source channels, <= 32 destination channels, window <= 3x3, no dilation
+// Measured on the C2 layers (B = 32, single stream): a win for 16 source channels with a 3x3 window (16->16 at 160x160: 57 -> 49 us)
+// and for the parity classes of a stride-2 data gradient (16->32 at 320x320: 144 -> 116 us); NOT for 32 channels at stride 1
+// (32->32 3x3 at 80x80: 26 -> 34 us) or 1x1 windows (48->32: 34 -> 48 us) -- one round of loads per tap row and the per-block
+// weight staging / epilogue still dominate a 256-pixel block, so those stay on the tiled kernel (`all_shapes` = tests / tuning).
+bool thin_eligible(const dy_conv_desc* d, int mode, bool parity_class = false) {
+  static const bool off = getenv("DY_NO_CONV_THIN") != nullptr;
+  static const bool all_shapes = getenv("DY_CONV_THIN_ALL") != nullptr;
+  if (off || d->dtype != DY_BF16) return false;
+  if (!all_shapes && !parity_class && !(d->Cs == 16 && d->KH * d->KW > 1)) return false;
+  if (!(d->Cs == 16 || d->Cs == 32 || d->Cs == 48) || d->Cd > 32 || d->Cd % 8 != 0) return false;
+  if (d->KH > 3 || d->KW > 3 || d->dil != 1 || (mode == 1 && d->stride != 1)) return false;
+  if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || (long)d->N * d->Hd * d->Wd < 1024) return false;
+  return true;
+}
+
+int launch_thin(const dy_conv_desc* d, int mode, hipStream_t st, const dy_conv_desc* classes = nullptr, int ncls = 0) {
+  ConvP p;
+  fill_convp(p, d, classes, ncls);
+  p.tiles_n = 1;
+  p.nblk = dy_cdiv(p.M, THIN_BM);
+  if (p.ncls > 1) {
+    long acc = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+      p.cls[c].blk0 = (int)acc;
+      acc += dy_cdiv(p.cls[c].M, THIN_BM);
+    }
+    p.nblk = (int)acc;
+  }
+#define THIN(C_, M_) conv_thin_kernel<C_, M_><<<p.nblk, NTHREADS, 0, st>>>(p)
+  const int c16 = d->Cs / 16;
+  if (mode == 0) { if (c16 == 1) THIN(1, 0); else if (c16 == 2) THIN(2, 0); else THIN(3, 0); }
+  else { if (c16 == 1) THIN(1, 1); else if (c16 == 2) THIN(2, 1); else THIN(3, 1); }
+#undef THIN
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -747,6 +925,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
+  if (thin_eligible(d, 0)) return launch_thin(d, 0, st);
   return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : launch_conv<bf16_t, 0>(d, st);
 }
 
@@ -811,9 +990,13 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
           none_v2 = none_v2 && !e2;
         }
         if (all_v2) return dy_conv_v2_launch_classes(r, nc, stream);
-        if (none_v2)
+        if (none_v2) {
+          bool thin = true;
+          for (int i = 0; i < nc; ++i) thin = thin && thin_eligible(&r[i], 0, true);
+          if (thin) return launch_thin(&r[0], 0, (hipStream_t)stream, r, nc);
           return d->dtype == DY_F32 ? launch_conv<float, 0>(&r[0], (hipStream_t)stream, r, nc)
                                     : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc);
+        }
       }
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
         const dy_conv_desc* q = &c[i];
@@ -828,6 +1011,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;
+  if (thin_eligible(d, 1)) return launch_thin(d, 1, st);
   return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : launch_conv<bf16_t, 1>(d, st);
 }
 

@@ -68,6 +68,8 @@ PIPELINED = [(2, 64, 128, 40, 40, 3, 1, 1), (3, 128, 64, 32, 32, 3, 2, 1), (2, 6
              (6, 60, 62, 150, 147, 3, 1, 1),   # band weight gradient (64-channel 3x3, long pixel loop), ragged width / channels
              (24, 128, 128, 80, 72, 3, 1, 1), (24, 124, 64, 80, 72, 3, 1, 1), (24, 64, 128, 80, 72, 3, 1, 1),   # ... 128-channel variants
              (3, 256, 8, 37, 23, 1, 1, 0),     # thin 1x1 dgrad (ASFF weight_level convs)
+             (12, 16, 32, 41, 39, 3, 2, 1), (5, 32, 24, 37, 35, 3, 1, 1), (4, 16, 16, 40, 40, 1, 1, 0), (6, 32, 16, 36, 38, 3, 2, 1),
+             (3, 48, 16, 33, 30, 3, 1, 1),     # thin-layer kernel (A fragments straight from global memory): s1 / s2 / parity classes / ragged
              (2, 3, 16, 64, 64, 3, 2, 1), (2, 3, 64, 33, 47, 3, 2, 1)]   # stem: direct dot2 dgrad with planar dx
 
 
@@ -81,3 +83,29 @@ def test_conv_f32_exact_mfma(shape):
 def test_conv_bf16(shape):
     r = _case(torch.bfloat16, *shape)
     assert max(r.values()) < 1e-2, r
+
+
+THIN = [(12, 16, 32, 41, 39, 3, 2, 1), (5, 32, 24, 37, 35, 3, 1, 1), (4, 16, 16, 40, 40, 1, 1, 0), (6, 32, 16, 36, 38, 3, 2, 1),
+        (3, 48, 16, 33, 30, 3, 1, 1), (4, 32, 32, 40, 40, 3, 1, 1), (4, 48, 32, 40, 40, 1, 1, 0), (4, 16, 16, 48, 40, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", THIN, ids=lambda s: "x".join(map(str, s)))
+def test_conv_bf16_thin_route_all_shapes(shape):
+    """Every instantiation of the thin-layer kernel (16 / 32 / 48 source channels, forward and stride-1 data gradient): the default
+    dispatch only routes the shapes where it wins, DY_CONV_THIN_ALL=1 (read once per process) routes all eligible ones."""
+    import os
+    if os.environ.get("DY_CONV_THIN_ALL") is None:
+        pytest.skip("runs in the DY_CONV_THIN_ALL=1 subprocess of test_thin_kernel_subprocess")
+    r = _case(torch.bfloat16, *shape)
+    assert max(r.values()) < 1e-2, r
+
+
+def test_thin_kernel_subprocess():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DY_CONV_THIN_ALL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv_kernels.py"), "-q", "-x", "-k",
+                        "thin_route_all_shapes", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
