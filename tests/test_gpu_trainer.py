@@ -156,3 +156,36 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
         assert last < 0.6 * first, (first, last)
     finally:
         dy.set_compute_dtype(torch.float32)
+
+
+def test_side_streams_do_not_change_the_step():
+    """Weight gradients on the second stream + Detect levels on branch streams against everything on one stream: same start
+    state, same batches, three optimizer steps.  The schedules differ only in WHEN kernels run; the per-channel f64 atomics make
+    neither of them bit-reproducible, so the comparison is at f32 round-off (the gradients themselves are the same sums)."""
+    import bench
+    from dedark_yolo_amd import ops
+
+    def run(on):
+        tr = _tiny_trainer("SGD", batch=64)
+        ops.enable_wgrad_stream(on)
+        ops.enable_branch_streams(on)
+        losses = []
+        for i in range(3):
+            b = bench.synth_batch(50 + i, 4, 96, 20, "cuda")
+            tr.args.dark_param = b.pop("gamma")
+            b.pop("n_max")
+            loss, _ = tr.train_step(b, [0.01] * 3, 0.9)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, tr.flat.p.detach().clone(), tr.flat.g.detach().clone()
+
+    try:
+        l1, p1, g1 = run(True)
+        assert ops.wgrad_side_stream() is not None                      # the side stream really was in use
+        l0, p0, g0 = run(False)
+    finally:
+        ops.enable_wgrad_stream(True)
+        ops.enable_branch_streams(True)
+    assert np.allclose(l1, l0, rtol=2e-5, atol=1e-5), (l1, l0)
+    assert float((p1 - p0).abs().max()) <= 1e-5 * max(1.0, float(p0.abs().max()))
+    assert float((g1 - g0).abs().max()) <= 2e-4 * max(1e-3, float(g0.abs().max()))
