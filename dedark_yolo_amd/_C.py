@@ -41,6 +41,10 @@ _SIGS = {
     "dy_conv2d_dgrad": [C.POINTER(ConvDesc), vp],
     "dy_conv2d_wgrad": [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp,
                         i32, vp],
+    "dy_conv2d_wgrad_forked": [vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64,
+                               vp, i32, vp],
+    "dy_conv2d_bn_act_fwd": [C.POINTER(ConvDesc), i64, vp, vp, vp, vp, f32, f32, vp, i32, vp, i64, vp, i64, vp],
+    "dy_bn_act_bwd": [vp, i64, vp, i64, vp, vp, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp],
     "dy_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "dy_pack_item_blocks": [i32, i32, i32, i32],
     "dy_pack_weights_multi": [vp, i32, i64, vp],

@@ -428,3 +428,14 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   DY_LAUNCH_CHECK();
   return 0;
 }
+
+// both backward passes behind one call (aff = [scale | shift | mean | invstd], C floats each)
+extern "C" int dy_bn_act_bwd(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, const float* aff, const float* gamma, int act,
+                             double* sums, void* dz, int64_t dz_ld, float* dgamma, float* dbeta, int64_t pixels, int C, int dtype,
+                             void* stream) {
+  DY_CHECK(aff, "dy_bn_act_bwd: null affine buffer");
+  if (int e = dy_bn_act_bwd_reduce(dy, dy_ld, z, z_ld, aff, aff + C, aff + 2 * C, aff + 3 * C, act, 1, sums, pixels, C, dtype, stream))
+    return e;
+  return dy_bn_act_bwd_apply(dy, dy_ld, z, z_ld, aff, aff + C, aff + 2 * C, aff + 3 * C, gamma, act, 1, sums, dz, dz_ld, dgamma, dbeta,
+                             pixels, C, dtype, stream);
+}

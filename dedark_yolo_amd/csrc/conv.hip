@@ -1127,3 +1127,28 @@ extern "C" int dy_unpack_wgrad(const float* dwp, float* g, int Cout, int Cin, in
   DY_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- merged entries: the same launches as the separate calls, one foreign-function call instead of two or three.  The step of
+// BASELINE configs[1] issues ~700 launches from Python at ~10 us of interpreter + ctypes time each and had become host-bound
+// (tools/host_time.py: 9.6 ms to issue a step the GPU finishes in 9.9 ms).
+extern "C" int dy_conv2d_bn_act_fwd(const dy_conv_desc* d, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, float* aff, int act, const void* residual,
+                                    int64_t res_ld, void* y, int64_t y_ld, void* stream) {
+  DY_CHECK(d && d->stats && d->dst && aff, "dy_conv2d_bn_act_fwd: needs a raw-output buffer, statistics and the affine buffer");
+  if (int e = dy_conv2d_fwd(d, stream)) return e;
+  const int C = d->Cd;
+  if (int e = dy_bn_finalize(d->stats, count, gamma, beta, running_mean, running_var, momentum, eps, aff, aff + C, aff + 2 * C,
+                             aff + 3 * C, C, stream))
+    return e;
+  return dy_bn_act_fwd(d->dst, d->dst_ld, aff, aff + C, act, residual, res_ld, y, y_ld, (int64_t)d->N * d->Hd * d->Wd, C, d->dtype, stream);
+}
+
+extern "C" int dy_conv2d_wgrad_forked(void* wait_for, const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz,
+                                      int64_t dz_ld, int Ho, int Wo, int Cout_pad, int KH, int KW, int stride, int pad, int dil,
+                                      int Cout, int Cin, float* scratch, int64_t scratch_elems, float* g_oihw, int dtype,
+                                      void* stream) {
+  if (wait_for != stream)                      // (a null handle is a stream too: the default stream)
+    if (int e = dy_stream_fork(wait_for, stream)) return e;
+  return dy_conv2d_wgrad(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
+                         scratch_elems, g_oihw, dtype, stream);
+}

@@ -13,6 +13,7 @@ from . import _C
 from ._C import ACT_LEAKY, ACT_NONE, ACT_SILU, ConvDesc, DetMaps, call
 
 _compute_dtype = torch.float32
+_pack_generation = 0        # bumped whenever _pack() allocates a new packed copy
 _weights_epoch = 0          # bumped by the fused optimizer (it writes parameters through raw pointers)
 
 
@@ -78,19 +79,18 @@ def zeros_nhwc(B, C_, H, W, dtype, device):
 def ld_of(t):
     """Pixel stride (elements) of an NHWC view [B,C,H,W]; raises if `t` is not such a view."""
     B, Cc, H, W = t.shape
-    if Cc > 1 and t.stride(1) != 1:
+    sb, sc, sh, sw = t.stride()              # one call: this runs ~400 times per training step
+    if Cc > 1 and sc != 1:
         raise RuntimeError(f"dedark_yolo_amd: expected an NHWC (channels_last) view, got strides {t.stride()} for {tuple(t.shape)}")
-    ld = None
     if W > 1:
-        ld = t.stride(3)
+        ld = sw
     elif H > 1:
-        ld = t.stride(2)
+        ld = sh
     elif B > 1:
-        ld = t.stride(0)
+        ld = sb
     else:
         ld = Cc
-    ok = ld >= Cc and (W == 1 or t.stride(3) == ld) and (H == 1 or t.stride(2) == W * ld) and (B == 1 or t.stride(0) == H * W * ld)
-    if not ok:
+    if not (ld >= Cc and (W == 1 or sw == ld) and (H == 1 or sh == W * ld) and (B == 1 or sb == H * W * ld)):
         raise RuntimeError(f"dedark_yolo_amd: not a dense NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
     return ld
 
@@ -175,6 +175,9 @@ def _pack(weight, cout_pad, cin_pad, transposed, dtype):
     if hit is not None and hit[0] == tag:
         return hit[1]
     Co, Ci, KH, KW = weight.shape
+    if hit is None:
+        global _pack_generation
+        _pack_generation += 1                  # a new packed copy exists: PackPlan must re-collect
     out = hit[1] if hit is not None else torch.empty(cout_pad * KH * KW * cin_pad, dtype=dtype, device=weight.device)
     w32 = weight.detach()
     if w32.dtype != torch.float32 or not w32.is_contiguous():
@@ -205,10 +208,20 @@ class PackPlan:
         return ent
 
     def repack(self, model):
-        ent = self._collect(model)
+        # the entry list only changes when _pack() creates a new packed copy (first use of a layout) or the parameters move:
+        # walking model.parameters() and rebuilding the signature cost ~1 ms of host time per step
+        key = (id(model), _pack_generation)
+        if key != getattr(self, "_ent_key", None):
+            self._ent = self._collect(model)
+            self._ent_sig = tuple((w.data_ptr(), out.data_ptr(), k) for w, k, out in self._ent)
+            self._ent_key = key
+        ent = self._ent
         if not ent:
             return
-        sig = tuple((w.data_ptr(), out.data_ptr(), key) for w, key, out in ent)
+        sig = self._ent_sig
+        if any(w.data_ptr() != sg[0] for (w, _, _), sg in zip(ent[:4], sig[:4])):      # parameters re-bound (model.to(), new flat state)
+            self._ent_key = None
+            return self.repack(model)
         if sig != self.sig:
             items = (_C.PackItem * len(ent))()
             blk = 0
@@ -246,22 +259,14 @@ class ConvCtx:
 
 
 def _conv_desc(src, w, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, KH, KW, stride, pad, dil, scale, shift, act, stats, accumulate, dtype):
-    d = ConvDesc()
-    d.src, d.src_ld = src.data_ptr(), ld_of(src)
-    d.N, d.Hs, d.Ws, d.Cs = N, Hs, Ws, Cs
-    d.w = w.data_ptr()
+    # positional construction (field order of _C.ConvDesc): ~4x cheaper than 25 attribute stores, and this runs twice per conv
     if dst is not None:
-        d.dst, d.dst_ld = dst.data_ptr(), ld_of(dst)
+        dptr, dld = dst.data_ptr(), ld_of(dst)
     else:                                   # dgrad into a planar tensor (dst_planar is set by the caller)
-        d.dst, d.dst_ld = None, Cd
-    d.Hd, d.Wd, d.Cd = Hd, Wd, Cd
-    d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
-    d.scale, d.shift = ptr(scale), ptr(shift)
-    d.act = act
-    d.stats = ptr(stats)
-    d.accumulate = 1 if accumulate else 0
-    d.dtype = dt_id(dtype)
-    return d
+        dptr, dld = None, Cd
+    return ConvDesc(src.data_ptr(), ld_of(src), N, Hs, Ws, Cs, w.data_ptr(), dptr, dld, Hd, Wd, Cd, KH, KW, stride, pad, dil,
+                    None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), act,
+                    None if stats is None else stats.data_ptr(), 1 if accumulate else 0, dt_id(dtype))
 
 
 _bn_pending = {}
@@ -308,19 +313,27 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         stats = arena.alloc(2 * cout_pad * _C.STATS_REPLICAS, dev)
         d = _conv_desc(x, wp, z, B, H, W, cin_pad, Ho, Wo, cout_pad, KH, KW, stride, pad, dil, None, None, ACT_NONE, stats,
                        False, dtype)
-        _C._prof is not None and _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * B * Ho * Wo * Cout * KH * KW * Cin,
-                    bytes=float((B * H * W * Cin + B * Ho * Wo * Cout + Cout * KH * KW * Cin) * x.element_size()))
-        call("dy_conv2d_fwd", C.byref(d), stream())
         aff = torch.empty((4, cout_pad), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
-        call("dy_bn_finalize", ptr(stats), B * Ho * Wo, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-             ptr(bn.running_var), float(bn.momentum), float(bn.eps), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]),
-             cout_pad, stream())
+        pa, sa = aff.data_ptr(), 4 * cout_pad
+        pixels = B * Ho * Wo
         _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
         y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
-        _C._prof is not None and _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
-                    bytes=float(B * Ho * Wo * cout_pad * x.element_size() * (3 if residual is not None else 2)))
-        call("dy_bn_act_fwd", ptr(z), ld_of(z), ptr(aff[0]), ptr(aff[1]), act, ptr(residual),
-             ld_of(residual) if residual is not None else 0, ptr(y), ld_of(y), B * Ho * Wo, cout_pad, dt_id(dtype), stream())
+        st = stream()
+        rp, rld = (residual.data_ptr(), ld_of(residual)) if residual is not None else (None, 0)
+        bp = bn._parameters
+        if _C._prof is None:
+            # conv (raw z + statistics) -> finalize -> affine/activation/residual: three launches, ONE foreign call
+            call("dy_conv2d_bn_act_fwd", C.byref(d), pixels, ptr(bp["weight"]), ptr(bp["bias"]), ptr(bn.running_mean), ptr(bn.running_var),
+                 float(bn.momentum), float(bn.eps), pa, act, rp, rld, y.data_ptr(), ld_of(y), st)
+        else:                               # per-entry timing (bench.py roofline leg, tools/layer_profile.py)
+            _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
+                        bytes=float((B * H * W * Cin + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
+            call("dy_conv2d_fwd", C.byref(d), st)
+            call("dy_bn_finalize", ptr(stats), pixels, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                 ptr(bn.running_var), float(bn.momentum), float(bn.eps), pa, pa + sa, pa + 2 * sa, pa + 3 * sa, cout_pad, st)
+            _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
+                        bytes=float(pixels * cout_pad * x.element_size() * (3 if residual is not None else 2)))
+            call("dy_bn_act_fwd", ptr(z), ld_of(z), pa, pa + sa, act, rp, rld, ptr(y), ld_of(y), pixels, cout_pad, dt_id(dtype), st)
         if ctx is not None:
             ctx.z, ctx.aff, ctx.y = z, aff, None
     else:
@@ -494,18 +507,22 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
         sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)
         pa, sa = aff.data_ptr(), 4 * cout_pad                               # rows of aff: scale, shift, mean, invstd
-        _C._prof is not None and _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
-        call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
-             ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
         dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         gw_, gb_ = _grad_dst(bn.weight), _grad_dst(bn.bias)
         direct = gw_ is not None and gb_ is not None
         if not direct:
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
-        _C._prof is not None and _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
-        call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
-             ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
+        if _C._prof is None:
+            call("dy_bn_act_bwd", dy.data_ptr(), ld_of(dy), z.data_ptr(), ld_of(z), pa, ptr(bn._parameters["weight"]), ctx.act,
+                 sums.data_ptr(), dz.data_ptr(), ld_of(dz), gw_.data_ptr(), gb_.data_ptr(), pixels, cout_pad, did, st)
+        else:
+            _C.set_meta(kind="bn_act_bwd_reduce", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 2))
+            call("dy_bn_act_bwd_reduce", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
+                 ctx.act, 1, ptr(sums), pixels, cout_pad, did, st)
+            _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
+            call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
+                 ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
         if not direct:
             _add_pgrad(tape, bn.weight, gw_)
             _add_pgrad(tape, bn.bias, gb_)
@@ -541,7 +558,8 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         side = wgrad_side_stream(dev) if gd is not None else None
         st_w = st
         if side is not None:
-            _side_wait_main()                          # dz (and, for a first step, x) are ready
+            if _C._prof is not None:
+                _side_wait_main()                      # dz (and, for a first step, x) are ready
             if not _wg_side.cb_queued:                 # join at the end of this backward pass even without a trainer
                 try:
                     torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
@@ -557,6 +575,8 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
         if side is not None and _C._prof is not None:
             with torch.cuda.stream(side):              # per-call timing: the events must sit on the launch stream
                 call("dy_conv2d_wgrad", *wargs, st_w)
+        elif side is not None:
+            call("dy_conv2d_wgrad_forked", st, *wargs, st_w)        # fork from the compute stream + wgrad: one foreign call
         else:
             call("dy_conv2d_wgrad", *wargs, st_w)
         if side is not None:

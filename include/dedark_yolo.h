@@ -254,6 +254,21 @@ int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, f
 int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream);
 /* acc += g: gradient accumulation over `accumulate` batches (nbs / batch, U/engine/trainer.py:248,340-342) */
 int dy_grad_accumulate(float* acc, const float* g, int64_t n, void* stream);
+/* Merged entries: exactly the launches of the separate calls, behind ONE foreign-function call (the training step of BASELINE
+ * configs[1] is ~700 launches issued from Python and had become host-bound).
+ *   dy_conv2d_bn_act_fwd  = dy_conv2d_fwd(d: dst = raw z, stats) + dy_bn_finalize + dy_bn_act_fwd(z -> y); aff = 4*Cd floats
+ *                           [scale | shift | mean | invstd] (kept for the backward pass)
+ *   dy_bn_act_bwd         = dy_bn_act_bwd_reduce + dy_bn_act_bwd_apply with the same aff buffer
+ *   dy_conv2d_wgrad_forked = dy_stream_fork(wait_for, stream) + dy_conv2d_wgrad on `stream` */
+int dy_conv2d_bn_act_fwd(const dy_conv_desc* d, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* aff, int act, const void* residual, int64_t res_ld,
+                         void* y, int64_t y_ld, void* stream);
+int dy_bn_act_bwd(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, const float* aff, const float* gamma, int act,
+                  double* sums, void* dz, int64_t dz_ld, float* dgamma, float* dbeta, int64_t pixels, int C, int dtype, void* stream);
+int dy_conv2d_wgrad_forked(void* wait_for, const void* x, int64_t x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz,
+                           int64_t dz_ld, int Ho, int Wo, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout,
+                           int Cin, float* scratch, int64_t scratch_elems, float* g_oihw, int dtype, void* stream);
+
 /* Stream plumbing of the backward pass (no counterpart in the single-stream reference): `to` waits for everything issued so far
  * on `from` (hipEventRecord on an internal ring of timing-free events + hipStreamWaitEvent; no host synchronisation).  Used to
  * run the weight gradients of a conv on a second HIP stream next to its dgrad -> BatchNorm-backward chain. */
