@@ -8,6 +8,7 @@ autograd.Function so torch.autograd links modules while everything inside a modu
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -558,6 +559,9 @@ class ConvBlock(nn.Module):
         self.conv_block = nn.Sequential(*layers)
 
 
+_EXTRACTOR_F32 = os.environ.get("DY_EXTRACTOR_F32") is not None
+
+
 class ExtractParameters2(nn.Module):
     """CNN parameter regressor (reference common.py:52-78): 5 x (conv3x3 s2 + LeakyReLU) 256^2 -> 8^2, fc 2048-64-15."""
 
@@ -602,12 +606,17 @@ class lowlight_recovery(DyModule):
         f32 = torch.float32
         A, I = getattr(self, "_A", None), getattr(self, "_I", None)
         st = stream()
-        r8 = torch.empty((B, 256, 256, 8), dtype=f32, device=dev).permute(0, 3, 1, 2)
-        call("dy_image_to_nhwc8", ptr(x), B, H, W, ptr(r8), 256, 256, ops.dt_id(f32), st)
+        # the five stride-2 convs of the regressor run in the compute dtype (the reference's autocast covers them as well); the two
+        # fully connected layers and all filter math stay fp32.  DY_EXTRACTOR_F32=1 keeps the whole regressor in fp32.
+        xd = f32 if _EXTRACTOR_F32 else ops.get_compute_dtype()
+        r8 = torch.empty((B, 256, 256, 8), dtype=xd, device=dev).permute(0, 3, 1, 2)
+        call("dy_image_to_nhwc8", ptr(x), B, H, W, ptr(r8), 256, 256, ops.dt_id(xd), st)
         t = r8[:, :3]
         ex = self.extractor
         for blk in ex.conv_layers:
             t = plain_conv_fwd(tape, blk.conv_block[0], t, act=ACT_LEAKY)
+        if xd != f32:
+            t = as_nhwc(t, f32)                          # [B,32,8,8]: 64 K values
         w1 = ex.fc1.weight.detach().view(64, 32, 8, 8)
         t = conv_forward(tape, t, w1, ex.fc1.bias, None, ACT_LEAKY, 1, 0, 1, False, owner=ex.fc1.weight)
         w2 = ex.fc2.weight.detach().view(15, 64, 1, 1)
@@ -647,8 +656,12 @@ class lowlight_recovery(DyModule):
         call("dy_filter_params_bwd", ptr(feat), fl, ptr(dparams), ptr(dfeat), B, st)
         g = conv_backward(tape, dfeat[:, :15])            # fc2
         g = conv_backward(tape, g)                        # fc1
+        if not _EXTRACTOR_F32 and ops.get_compute_dtype() != f32:
+            g = as_nhwc(g, ops.get_compute_dtype())
         for k in reversed(range(5)):
             g = conv_backward(tape, g, need_dx=(k > 0 or need_dx))
         if need_dx:
+            if g.dtype != f32:
+                g = as_nhwc(g, f32)
             call("dy_resize_bwd", ptr(g), ld_of(g), B, H, W, 256, 256, ptr(dx), st)
         return dx
