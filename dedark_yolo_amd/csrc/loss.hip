@@ -38,6 +38,17 @@ __device__ inline const T* row_ptr(const Maps& m, int b, int lvl, int cell) {
   return reinterpret_cast<const T*>(m.map[lvl]) + ((long)b * m.h[lvl] * m.w[lvl] + cell) * m.ld[lvl];
 }
 
+// n consecutive channels of one anchor row as floats: 16-byte loads where the row allows it (rows start 16-byte aligned and
+// c0 is a multiple of the vector width everywhere below); the per-element 2-byte loads made the loss kernels instruction-bound
+template <typename T>
+__device__ inline void load_run(const T* r, int c0, int n, long ld, float* out) {
+  constexpr int VE = DT<T>::VE;
+  int k = 0;
+  if ((c0 % VE) == 0)
+    for (; k + VE <= n && c0 + k + VE <= ld; k += VE) ldvec<T>(r + c0 + k, out + k);
+  for (; k < n; ++k) out[k] = DT<T>::ld(r + c0 + k);
+}
+
 // ---- targets ---------------------------------------------------------------------------------------------------------
 __global__ void prepare_targets_kernel(const float* __restrict__ bidx, const float* __restrict__ cls,
                                        const float* __restrict__ bb, int n, int B, int n_max, float W, float H,
@@ -76,8 +87,7 @@ __global__ void decode_kernel(Maps m, float* __restrict__ pred) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     float x[REG], p[REG];
-#pragma unroll
-    for (int k = 0; k < REG; ++k) x[k] = DT<T>::ld(r + s * REG + k);
+    load_run<T>(r, s * REG, REG, m.ld[lvl], x);
     d[s] = dy_softmax_expect(x, REG, p);
   }
   float* o = pred + i * 4;
@@ -167,28 +177,40 @@ __global__ __launch_bounds__(256) void tal_metrics_kernel(Maps m, const float* _
   // ordered compaction of the elements that can ever enter the heap: comp(v, v0)
   const float v0 = s_v0;
   int* cl = cand + base;
-  for (int a0 = TOPK; a0 < m.A; a0 += 256) {
-    int a = a0 + tid;
-    bool keep = a < m.A && topk_comp(al[a], v0);
-    unsigned long long bal = __ballot(keep);
-    int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
+  // (thread t owns the contiguous anchors [TOPK + t*chunk, +chunk): count, one block-wide exclusive scan, write -- the ordered
+  //  compaction used to be 33 rounds of ballot + three block barriers each)
+  {
+    const int chunk = (m.A - TOPK + 255) / 256;
+    const int a_lo = TOPK + tid * chunk, a_hi = min(a_lo + chunk, m.A);
+    int cnt = 0;
+    for (int a = a_lo; a < a_hi; ++a) cnt += topk_comp(al[a], v0) ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave_cnt[wave] = incl;
     __syncthreads();
-    int off = s_total;
+    int off = incl - cnt;
     for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
-    if (keep) cl[off + before] = a;
-    __syncthreads();
-    if (tid == 0) s_total += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    for (int a = a_lo; a < a_hi; ++a)
+      if (topk_comp(al[a], v0)) cl[off++] = a;
+    if (tid == 255) s_total = off;                        // the last thread's end = total
     __syncthreads();
   }
-  // sequential heap-select over the candidates (wave 0; lanes broadcast candidates, lane 0 mutates the heap)
+  // sequential heap-select over the candidates (wave 0; lanes broadcast candidates, lane 0 mutates the heap).  The heap minimum
+  // only grows, so a candidate that does not beat the minimum at the start of its 64-wide chunk never will: only the others are
+  // visited (a large box has thousands of candidates and 10 winners).
   if (wave == 0) {
     const int total = s_total;
     for (int c0 = 0; c0 < total; c0 += 64) {
       int idx = (c0 + lane < total) ? cl[c0 + lane] : -1;
       float val = idx >= 0 ? al[idx] : 0.f;
-      int n = total - c0 < 64 ? total - c0 : 64;
-      for (int t = 0; t < n; ++t) {
+      unsigned long long todo = __ballot(idx >= 0 && topk_comp(val, hv[0]));
+      while (todo) {
+        const int t = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         float vt = __shfl(val, t, 64);
         int it = __shfl(idx, t, 64);
         if (topk_comp(vt, hv[0])) {
@@ -295,7 +317,12 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(Maps m, const float* __re
     const float wgt = f ? norm[i] : 0.f;
     const int lb = label[i];
     a_ts = wgt;
-    for (int c = 0; c < m.nc; ++c) a_bce += dy_bce(DT<T>::ld(r + 4 * REG + c), (f && c == lb) ? wgt : 0.f);
+    for (int c0 = 0; c0 < m.nc; c0 += 8) {
+      float xc[8];
+      const int n = m.nc - c0 < 8 ? m.nc - c0 : 8;
+      load_run<T>(r, 4 * REG + c0, n, m.ld[lvl], xc);
+      for (int e = 0; e < n; ++e) a_bce += dy_bce(xc[e], (f && c0 + e == lb) ? wgt : 0.f);
+    }
     if (f) {
       const float st = m.stride[lvl];
       float tb[4] = {tbox[i * 4] / st, tbox[i * 4 + 1] / st, tbox[i * 4 + 2] / st, tbox[i * 4 + 3] / st};
@@ -306,8 +333,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(Maps m, const float* __re
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         float x[REG];
-#pragma unroll
-        for (int k = 0; k < REG; ++k) x[k] = DT<T>::ld(r + s * REG + k);
+        load_run<T>(r, s * REG, REG, m.ld[lvl], x);
         float t = fminf(fmaxf(tgt[s], 0.f), (float)(REG - 1) - 0.01f);
         d += dy_dfl_side(x, t, nullptr, nullptr);
       }
@@ -361,14 +387,33 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Maps m, char* d0, char* d
   const bool f = fg[i] != 0;
   const float wgt = f ? norm[i] : 0.f;
   const int lb = label[i];
-  for (int c = 0; c < m.nc; ++c) {
-    float x = DT<T>::ld(r + 4 * REG + c);
-    float t = (f && c == lb) ? wgt : 0.f;
-    DT<T>::st(o + 4 * REG + c, go * hc * (dy_sigmoid(x) - t));
+  constexpr int VE = DT<T>::VE;
+  const bool vec_ok = (pad_to % VE) == 0 && (dld * (long)sizeof(T)) % 16 == 0;      // always true for our padded NHWC gradient maps
+  // class logits, then zeros up to the padded width: VE channels per 16-byte store
+  for (int c0 = 4 * REG; c0 < pad_to; c0 += VE) {
+    float x[VE], g[VE];
+    const int n = 4 * REG + m.nc - c0;                  // real channels left in this vector (may be <= 0)
+    load_run<T>(r, c0, n < VE ? (n > 0 ? n : 0) : VE, m.ld[lvl], x);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = c0 + e - 4 * REG;
+      g[e] = (e < n) ? go * hc * (dy_sigmoid(x[e]) - ((f && c == lb) ? wgt : 0.f)) : 0.f;
+    }
+    if (vec_ok) {
+      stvec<T>(o + c0, g);
+    } else {
+      for (int e = 0; e < VE && c0 + e < pad_to; ++e) DT<T>::st(o + c0 + e, g[e]);
+    }
   }
-  for (int c = 4 * REG + m.nc; c < pad_to; ++c) DT<T>::st(o + c, 0.f);
   if (!f) {
-    for (int c = 0; c < 4 * REG; ++c) DT<T>::st(o + c, 0.f);
+    float z[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) z[e] = 0.f;
+    for (int c = 0; c < 4 * REG; c += VE) {
+      if (vec_ok) stvec<T>(o + c, z);
+      else
+        for (int e = 0; e < VE; ++e) DT<T>::st(o + c + e, 0.f);
+    }
     return;
   }
   const float st = m.stride[lvl];
@@ -384,17 +429,24 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Maps m, char* d0, char* d
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     float x[REG], p[REG];
-#pragma unroll
-    for (int k = 0; k < REG; ++k) x[k] = DT<T>::ld(r + s * REG + k);
+    load_run<T>(r, s * REG, REG, m.ld[lvl], x);
     float e = dy_softmax_expect(x, REG, p);
     float t = fminf(fmaxf(tgt[s], 0.f), (float)(REG - 1) - 0.01f);
     int tl = (int)t;
     float wl = (float)(tl + 1) - t, wr = 1.f - wl;
+    float go_[REG];
 #pragma unroll
     for (int k = 0; k < REG; ++k) {
       float gdfl = p[k] - (k == tl ? wl : 0.f) - (k == tl + 1 ? wr : 0.f);
       float gbox = p[k] * ((float)k - e) * dd[s];
-      DT<T>::st(o + s * REG + k, kd * gdfl + gbox);
+      go_[k] = kd * gdfl + gbox;
+    }
+    if (vec_ok) {
+#pragma unroll
+      for (int k = 0; k < REG; k += VE) stvec<T>(o + s * REG + k, go_ + k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < REG; ++k) DT<T>::st(o + s * REG + k, go_[k]);
     }
   }
 }
@@ -413,8 +465,7 @@ __global__ void detect_decode_kernel(Maps m, float* __restrict__ y) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     float x[REG], p[REG];
-#pragma unroll
-    for (int k = 0; k < REG; ++k) x[k] = DT<T>::ld(r + s * REG + k);
+    load_run<T>(r, s * REG, REG, m.ld[lvl], x);
     d[s] = dy_softmax_expect(x, REG, p);
   }
   const float st = m.stride[lvl];
