@@ -617,9 +617,8 @@ class lowlight_recovery(DyModule):
             t = plain_conv_fwd(tape, blk.conv_block[0], t, act=ACT_LEAKY)
         if xd != f32:
             t = as_nhwc(t, f32)                          # [B,32,8,8]: 64 K values
-        w1 = ex.fc1.weight.detach().view(64, 32, 8, 8)
+        w1, w2 = self._fc_views()
         t = conv_forward(tape, t, w1, ex.fc1.bias, None, ACT_LEAKY, 1, 0, 1, False, owner=ex.fc1.weight)
-        w2 = ex.fc2.weight.detach().view(15, 64, 1, 1)
         feat = conv_forward(tape, t, w2, ex.fc2.bias, None, ACT_NONE, 1, 0, 1, False, owner=ex.fc2.weight)    # [B,15,1,1], ld 16
         params = torch.empty((B, 8), dtype=f32, device=dev)
         call("dy_filter_params_fwd", ptr(feat), ld_of(feat), ptr(params), B, st)
@@ -632,6 +631,19 @@ class lowlight_recovery(DyModule):
         if tape is not None:
             tape.push(dict(x=x, feat=feat, params=params, hp=hp, A=A, I=I))
         return out8[:, :3]
+
+    def _fc_views(self):
+        """The fully connected weights as conv weights ([64,32,8,8] window = whole input, [15,64,1,1]).  The view OBJECTS are kept:
+        the packed-weight cache lives on the tensor object, and a fresh view per step meant four re-pack launches per step."""
+        ex = self.extractor
+        key = (ex.fc1.weight.data_ptr(), ex.fc2.weight.data_ptr())
+        c = self.__dict__.get("_fc_view_cache")
+        if c is None or c[0] != key:
+            c = (key, ex.fc1.weight.detach().view(64, 32, 8, 8), ex.fc2.weight.detach().view(15, 64, 1, 1))
+            self.__dict__["_fc_view_cache"] = c
+            ops.register_pack_view(c[1])
+            ops.register_pack_view(c[2])
+        return c[1], c[2]
 
     def _bwd(self, tape, dout, needs=(False,)):
         s = tape.pop()

@@ -187,6 +187,14 @@ def _pack(weight, cout_pad, cin_pad, transposed, dtype):
     return out
 
 
+_extra_pack_views = []      # weakrefs of persistent weight VIEWS (fully connected layers run as convs) that PackPlan re-packs too
+
+
+def register_pack_view(t):
+    import weakref
+    _extra_pack_views.append(weakref.ref(t))
+
+
 class PackPlan:
     """Re-packs every cached packed weight of a model with one launch (dy_pack_weights_multi) right after the optimizer
     step wrote the f32 masters; the per-conv lazy path of _pack() then only ever hits its cache."""
@@ -199,7 +207,8 @@ class PackPlan:
 
     def _collect(self, model):
         ent = []
-        for w in model.parameters():
+        _extra_pack_views[:] = [r for r in _extra_pack_views if r() is not None]
+        for w in list(model.parameters()) + [r() for r in _extra_pack_views]:
             cache = w.__dict__.get("_dy_pack")
             if not cache or w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4:
                 continue
