@@ -989,13 +989,17 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
           all_v2 = all_v2 && e2;
           none_v2 = none_v2 && !e2;
         }
-        if (all_v2) return dy_conv_v2_launch_classes(r, nc, stream);
+        // ... where the classes are small: once a class alone fills the chip (C3: 256->512 at 80x80, B = 64, 400 tiles of
+        // 256x256 per class) one launch is SLOWER than four (560 vs 449 us) -- the short-K classes' blocks then crowd out the long ones
+        const long class_tiles = dy_cdiv((long)r[0].N * r[0].Hd * r[0].Wd, 256);
+        if (all_v2 && class_tiles <= 256) return dy_conv_v2_launch_classes(r, nc, stream);
         if (none_v2) {
           bool thin = true;
           for (int i = 0; i < nc; ++i) thin = thin && thin_eligible(&r[i], 0, true);
           if (thin) return launch_thin(&r[0], 0, (hipStream_t)stream, r, nc);
-          return d->dtype == DY_F32 ? launch_conv<float, 0>(&r[0], (hipStream_t)stream, r, nc)
-                                    : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc);
+          if (class_tiles <= 256)
+            return d->dtype == DY_F32 ? launch_conv<float, 0>(&r[0], (hipStream_t)stream, r, nc)
+                                      : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc);
         }
       }
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
