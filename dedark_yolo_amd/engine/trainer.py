@@ -311,6 +311,70 @@ class DetectionTrainer:
         self.step_count += 1
         return loss.detach(), items
 
+    # ---------------------------------------------------------------- checkpoints (state_dict based)
+    def save_model(self, wdir, epoch=0, fitness=None):
+        """last.pt (and best.pt when `fitness` is the best so far) with the keys of the reference checkpoint
+        (`U/engine/trainer.py:408-433`: epoch, best_fitness, model, ema, updates, optimizer, train_args, date, version).  The
+        reference pickles half-precision module objects; here `model` / `ema` are half-precision state_dicts (+ the model yaml),
+        which `YOLO(path)` / `DetectionModel.load` read back, and `optimizer` holds the flat momentum buffers of the fused step."""
+        import datetime
+        os.makedirs(wdir, exist_ok=True)
+        f = self.flat
+        best = getattr(self, "best_fitness", None)
+        if fitness is not None and (best is None or fitness >= best):
+            self.best_fitness = best = fitness
+        half = lambda sd: {k: (v.half() if v.dtype.is_floating_point else v.clone()).cpu() for k, v in sd.items()}
+        ops.flush_bn_counters()
+        ckpt = dict(epoch=int(epoch), best_fitness=best, model=half(self.model.state_dict()), ema=half(f.ema_state_dict(self.model)),
+                    updates=int(self.updates), yaml=getattr(self.model, "yaml", None), nc=getattr(self.model.model[-1], "nc", None),
+                    optimizer=dict(name=self.opt_name, momentum_buffer=f.m.cpu(), exp_avg_sq=None if f.m2 is None else f.m2.cpu(),
+                                   step_count=int(self.step_count), last_opt_step=int(self.last_opt_step), lr0=float(self.lr0),
+                                   momentum=float(self.momentum), weight_decay=float(self.weight_decay)),
+                    train_args={k: v for k, v in vars(self.args).items() if isinstance(v, (int, float, str, bool, type(None), list, tuple))},
+                    date=datetime.datetime.now().isoformat(), version="dedark_yolo_amd-1", state_dict=half(self.model.state_dict()))
+        last = os.path.join(wdir, "last.pt")
+        torch.save(ckpt, last)
+        if fitness is not None and best == fitness:
+            torch.save(ckpt, os.path.join(wdir, "best.pt"))
+        return last
+
+    def resume_training(self, ckpt):
+        """Restores parameters, EMA, optimizer buffers and counters from a `save_model` checkpoint (dict or path) and returns the
+        epoch to continue with (`U/engine/trainer.py:580-609`: start_epoch = ckpt['epoch'] + 1; half-precision weights are
+        converted back with .float() exactly like the reference does)."""
+        if isinstance(ckpt, (str, os.PathLike)):
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        f = self.flat
+        names = {id(p): k for k, p in self.model.named_parameters()}
+        msd, esd = ckpt["model"], ckpt.get("ema") or ckpt["model"]
+        for p, o, n, _ in f.slots:
+            k = names[id(p)]
+            f.p[o:o + n].copy_(msd[k].float().reshape(-1).to(f.p.device))
+            f.ema[o:o + n].copy_(esd[k].float().reshape(-1).to(f.p.device))
+        bnames = {id(b): k for k, b in self.model.named_buffers()}
+        o = 0
+        for b in f.buf_list:
+            n, k = b.numel(), bnames[id(b)]
+            f.buf_flat[o:o + n].copy_(msd[k].float().reshape(-1).to(f.p.device))
+            f.buf_ema[o:o + n].copy_(esd[k].float().reshape(-1).to(f.p.device))
+            o += ops.round_up(n, 4)
+        for k, b in self.model.named_buffers():                     # integer buffers (num_batches_tracked)
+            if not b.dtype.is_floating_point and k in msd:
+                b.copy_(msd[k].to(b.device))
+        opt = ckpt.get("optimizer")
+        if opt is not None:
+            if opt.get("name") != self.opt_name:
+                raise RuntimeError(f"resume: checkpoint was written by {opt.get('name')}, this trainer runs {self.opt_name}")
+            f.m.copy_(opt["momentum_buffer"].to(f.m.device))
+            if f.m2 is not None and opt.get("exp_avg_sq") is not None:
+                f.m2.copy_(opt["exp_avg_sq"].to(f.m2.device))
+            self.step_count, self.last_opt_step = int(opt.get("step_count", 0)), int(opt.get("last_opt_step", -1))
+            self.best_fitness = ckpt.get("best_fitness")
+        self.updates = int(ckpt.get("updates", 0))
+        ops.bump_weights_epoch()
+        self.pack_plan.repack(self.model)
+        return int(ckpt.get("epoch", -1)) + 1
+
     def train(self, loader, epochs=None):
         epochs = epochs or self.args.epochs
         nb = len(loader)

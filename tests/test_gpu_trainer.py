@@ -189,3 +189,40 @@ def test_side_streams_do_not_change_the_step():
     assert np.allclose(l1, l0, rtol=2e-5, atol=1e-5), (l1, l0)
     assert float((p1 - p0).abs().max()) <= 1e-5 * max(1.0, float(p0.abs().max()))
     assert float((g1 - g0).abs().max()) <= 2e-4 * max(1e-3, float(g0.abs().max()))
+
+
+def test_checkpoint_save_and_resume(tmp_path):
+    """save_model writes last.pt / best.pt with the reference's checkpoint keys (state_dict based); resume_training restores
+    parameters (through the reference's half-precision round trip), EMA, optimizer buffers and counters, and `YOLO(last.pt)`
+    reads the same file."""
+    import bench
+    from dedark_yolo_amd.engine.model import YOLO
+    tr = _tiny_trainer("SGD", batch=64)
+    for i in range(3):
+        b = bench.synth_batch(60 + i, 4, 96, 20, "cuda")
+        tr.args.dark_param = b.pop("gamma")
+        b.pop("n_max")
+        tr.train_step(b, [0.01] * 3, 0.9)
+    last = tr.save_model(str(tmp_path), epoch=4, fitness=0.25)
+    ck = torch.load(last, map_location="cpu", weights_only=False)
+    for k in ("epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "date", "version"):
+        assert k in ck, k
+    assert ck["epoch"] == 4 and ck["best_fitness"] == 0.25 and (tmp_path / "best.pt").exists()
+    assert all(v.dtype == torch.float16 for v in ck["model"].values() if v.dtype.is_floating_point)
+    tr2 = _tiny_trainer("SGD", batch=64)
+    assert tr2.resume_training(last) == 5
+    torch.cuda.synchronize()
+    want_p = tr.flat.p.half().float()
+    assert float((tr2.flat.p - want_p).abs().max()) == 0.0
+    assert float((tr2.flat.ema - tr.flat.ema.half().float()).abs().max()) == 0.0
+    assert float((tr2.flat.buf_flat - tr.flat.buf_flat.half().float()).abs().max()) == 0.0
+    assert torch.equal(tr2.flat.m, tr.flat.m) and tr2.updates == tr.updates and tr2.step_count == tr.step_count
+    b = bench.synth_batch(70, 4, 96, 20, "cuda")
+    tr2.args.dark_param = b.pop("gamma")
+    b.pop("n_max")
+    loss, _ = tr2.train_step(b, [0.01] * 3, 0.9)
+    assert np.isfinite(float(loss))
+    y = YOLO(last)                                          # the predictor reads the same file (weights_only load)
+    sd = y.model.state_dict()
+    k0 = next(k for k in sd if k.endswith("conv.weight"))
+    assert float((sd[k0].cpu() - ck["model"][k0].float()).abs().max()) == 0.0
