@@ -161,6 +161,42 @@ class GradBuckets:
         self._reset()
 
 
+class DevicePrefetcher:
+    """Uploads batch i+1 (host tensors of the dataloader's dict: uint8 images, cls, bboxes, batch_idx) on a copy stream while
+    step i runs on the compute stream (first piece).  Tensors that already live on the device pass through."""
+
+    def __init__(self, loader, device):
+        self.it = iter(loader)
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.nxt = None
+        self._load()
+
+    def _load(self):
+        try:
+            b = next(self.it)
+        except StopIteration:
+            self.nxt = None
+            return
+        with torch.cuda.stream(self.stream):
+            self.nxt = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) and not v.is_cuda else v) for k, v in b.items()}
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.nxt is None:
+            raise StopIteration
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
+        b = self.nxt
+        for v in b.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)                 # allocated on the copy stream, consumed (and freed) on the compute stream
+        self._load()                                 # the next upload overlaps the step that is about to be issued
+        return b
+
+
 class DetectionTrainer:
     """Minimal, faithful training loop for the detect task.  `train(loader)` consumes batch dicts with the reference schema
     (img uint8 [B,3,H,W] RGB, cls [N,1], bboxes [N,4] normalised xywh, batch_idx [N])."""
@@ -382,7 +418,7 @@ class DetectionTrainer:
         history = []
         nbs, bs = float(getattr(self.args, "nbs", 64)), max(int(getattr(self.args, "batch", 64)), 1)
         for epoch in range(epochs):
-            for i, batch in enumerate(loader):
+            for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
                 ni = i + nb * epoch
                 lr, mom = self.lr_factors(ni, nw, epoch, epochs)
                 if ni <= nw:                                   # trainer.py:320-322: accumulate ramps from 1 to nbs / batch

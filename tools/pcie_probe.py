@@ -49,5 +49,20 @@ for pin in (True, False):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print(f"{mode:14s}: {1e3 * dt:7.3f} ms/step  {32 / dt:8.1f} img/s", flush=True)
+    if pin:                                           # the trainer's one-ahead upload on a copy stream (engine/trainer.py)
+        from dedark_yolo_amd.engine.trainer import DevicePrefetcher
+        n = 60
+        src = [host[i % 2] for i in range(n + 10)]
+        it = DevicePrefetcher(src, tr.device)
+        for i, b in enumerate(it):
+            if i == 10:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            b = dict(b)
+            tr.args.dark_param = b["gamma"]
+            tr.train_step(b)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"{'pinned + prefetch':14s}: {1e3 * dt:7.3f} ms/step  {32 / dt:8.1f} img/s", flush=True)
     if not pin:
         break
