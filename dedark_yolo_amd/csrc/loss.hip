@@ -670,7 +670,7 @@ extern "C" int dy_preprocess_batch(const uint8_t* img, float* img_out, float* cl
                                    int dedark, double* mse_acc, int64_t n, void* stream) {
   DY_CHECK(img && img_out && n > 0, "dy_preprocess_batch: bad args");
   long b = (n + 255) / 256;
-  int blocks = (int)(b > 2048 ? 2048 : b);
+  int blocks = (int)(b > 1024 ? 1024 : b);           // one f64 atomic per block on one address at the end
   preprocess_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(img, img_out, clean_out, dark_param, lowlight, dedark, mse_acc, n);
   DY_LAUNCH_CHECK();
   return 0;

@@ -390,7 +390,8 @@ _wg_scratch = {}
 
 def wgrad_scratch(device, elems=32 << 20, tag=0):
     """Reusable f32 workspace for the split-pixel partial tiles of dy_conv2d_wgrad (128 MiB; stream-ordered reuse, one per
-    launch stream: tag 0 = the compute stream, tag 1 = the weight-gradient side stream)."""
+    launch stream: `tag` = the raw stream handle.  A shared workspace was a race once the Detect levels ran on branch streams
+    with gradients handed back to autograd -- their weight gradients then run on three streams at once)."""
     t = _wg_scratch.get((device, tag))
     if t is None or t.numel() < elems:
         t = torch.empty(elems, dtype=torch.float32, device=device)
@@ -576,7 +577,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
                 except RuntimeError:
                     pass
             st_w = side.cuda_stream
-        scratch = wgrad_scratch(dev, tag=0 if side is None else 1)
+        scratch = wgrad_scratch(dev, tag=st_w)         # one workspace per launch stream: Detect's levels may run their wgrads side by side
         _C._prof is not None and _C.set_meta(kind="conv_wgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                     bytes=float((B * H * W * Cin + pixels * Cout) * x.element_size() + Cout * KH * KW * Cin * 4))
         wargs = (ptr(x), ld_of(x), B, H, W, cin_pad, ptr(dz), ld_of(dz), Ho, Wo, cout_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, Cout, Cin,
