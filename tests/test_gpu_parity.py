@@ -346,3 +346,19 @@ def test_loss_with_empty_targets_vs_oracle(case):
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     if case == "no_boxes":
         assert float(items[0]) == 0.0 and float(items[2]) == 0.0
+
+
+def test_model_gradients_with_branch_streams_and_autograd_gradients():
+    """The Detect levels on branch streams while the gradients go back through autograd (no trainer, no flat buffer): the three
+    levels then run their weight gradients on three streams at once -- every one needs its own split-K workspace (a shared one
+    produced garbage in model.26.cv2.1.0.conv.weight).  Same bounds as the single-stream case above."""
+    from dedark_yolo_amd import ops
+    from parity_helpers import model_parity_case
+    ops.enable_branch_streams(True)
+    try:
+        r = model_parity_case("yolov8.yaml", "l", None, 404, 128, 4, [3, 2, 5, 1], fp64=True)
+    finally:
+        ops.enable_branch_streams(False)
+    assert abs(r["loss"] - r["oracle_loss"]) <= 1e-4 * abs(r["oracle_loss"])
+    assert r["grad_finite"] and r["n_nograd"] == 0
+    assert r["median_grad_rel"] < 1e-2 and r["worst_grad_rel"] < 0.1, r["worst5"]
