@@ -21,6 +21,8 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d);
 int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
 int dy_conv_v2_launch_classes(const dy_conv_desc* classes, int ncls, void* stream);
 // band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
+bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode);
+int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream);
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
 int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
 // pipelined bf16 weight gradient (wgrad_v2.hip)
@@ -922,6 +924,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   const int wo = (d->Ws + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
   if (dy_dense_fwd_eligible(d)) return dy_dense_fwd_launch(d, stream);
+  if (dy_conv_v4_eligible(d, 0)) return dy_conv_v4_launch(d, 0, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
@@ -1005,13 +1008,15 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
         const dy_conv_desc* q = &c[i];
         int e;
-        if (dy_conv_v2_eligible(q)) e = dy_conv_v2_launch(q, 0, stream);
+        if (dy_conv_v4_eligible(q, 0)) e = dy_conv_v4_launch(q, 0, stream);
+        else if (dy_conv_v2_eligible(q)) e = dy_conv_v2_launch(q, 0, stream);
         else e = q->dtype == DY_F32 ? launch_conv<float, 0>(q, (hipStream_t)stream) : launch_conv<bf16_t, 0>(q, (hipStream_t)stream);
         if (e) return e;
       }
       return 0;
     }
   }
+  if (dy_conv_v4_eligible(d, 1)) return dy_conv_v4_launch(d, 1, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;

@@ -24,6 +24,48 @@ constexpr int image_bytes() { return BN * pitch<BM>(); }
 
 __device__ inline uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 
+// Store phase: the transposed image [BN cols][BM rows] (pitch<BM>() bytes per column) -> HBM.  Unit = 16 pixels x 32 channels
+// per wave instruction; NW waves share the units.  The caller has synchronised the block after writing the image.
+template <int BM, int BN, int NW, typename OffFn>
+__device__ inline void store_image(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, bf16_t* dst,
+                                   OffFn off) {
+  constexpr int PT = pitch<BM>();
+  constexpr int UP = BM / 16, UC = BN / 32;
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int u = wave; u < UP * UC; u += NW) {
+    const int pt = u / UC, ct = u - pt * UC;
+    const int cb = ct * 32 + 8 * g;                // first channel of this lane's 8-channel vector
+    const char* base = smem + (cb + tq) * PT + (pt * 16 + 4 * tp) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 4 * PT));
+    const long m = m0 + pt * 16 + li;
+    const int n = n0 + cb;
+    if (m < M && n < Cd) {
+      u32x4 v;
+      v[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      v[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      v[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      v[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      bf16_t* o = dst + off(m) + n;
+      if (n + 8 <= Cd) {
+        if (accumulate) {
+          float x[8], y[8];
+          ldvec<bf16_t>(o, x);
+          ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += y[e];
+          stvec<bf16_t>(o, x);
+        } else {
+          *reinterpret_cast<u32x4*>(o) = v;
+        }
+      } else {                                     // ragged channel tail (never happens for padded views)
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+        for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+      }
+    }
+  }
+}
+
 // Block tile BM x BN on WM x WN waves (wave tile 32*TM x 32*TN).  `off(m)` = element offset of output pixel m.
 template <int BM, int BN, int WM, int WN, int TM, int TN, typename OffFn>
 __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int wn, int lane, int wave, long m0, int n0, long M, int Cd,
@@ -67,41 +109,7 @@ __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int
     }
   }
   __syncthreads();
-  // ---- store phase: unit = 16 pixels x 32 channels per wave instruction
-  constexpr int UP = BM / 16, UC = BN / 32;
-  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int u = wave; u < UP * UC; u += WM * WN) {
-    const int pt = u / UC, ct = u - pt * UC;
-    const int cb = ct * 32 + 8 * g;                // first channel of this lane's 8-channel vector
-    const char* base = smem + (cb + tq) * PT + (pt * 16 + 4 * tp) * 2;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 4 * PT));
-    const long m = m0 + pt * 16 + li;
-    const int n = n0 + cb;
-    if (m < M && n < Cd) {
-      u32x4 v;
-      v[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-      v[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-      v[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-      v[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-      bf16_t* o = dst + off(m) + n;
-      if (n + 8 <= Cd) {
-        if (accumulate) {
-          float x[8], y[8];
-          ldvec<bf16_t>(o, x);
-          ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] += y[e];
-          stvec<bf16_t>(o, x);
-        } else {
-          *reinterpret_cast<u32x4*>(o) = v;
-        }
-      } else {                                     // ragged channel tail (never happens for padded views)
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-        for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
-      }
-    }
-  }
+  store_image<BM, BN, WM * WN>(smem, lane, wave, m0, n0, M, Cd, accumulate, dst, off);
 }
 
 }  // namespace dy_epi

@@ -1,0 +1,427 @@
+// Phase-interleaved implicit-GEMM convolution for the wide bf16 layers (>= 256 output channels): forward and stride-1 data gradient
+// of nn.Conv2d inside Conv / Bottleneck / Detect (ultralytics/nn/modules/conv.py:38-55, block.py:553-565, head.py:40-46).
+//
+// conv_v2.hip keeps one barrier per 64-deep K-step and lets both waves of a SIMD run the same program in lockstep: the counters
+// showed 22-30 % MFMA-busy with 38-56 % of the wave cycles parked at the barrier / vmcnt(0).  This kernel is built around the
+// other structure the CDNA4 playbook describes for one block per CU:
+//   * 256 x 256 block tile, K-step 64, 8 waves = 2 groups of 4 (one wave of each group per SIMD).  The groups run the SAME
+//     program one barrier apart (group 1 executes one extra s_barrier before the loop, group 0 one after it): while one wave
+//     of a SIMD issues its 16 MFMAs of a phase the other one issues the LDS reads + DMA of its next phase;
+//   * a K-step is 4 phases, each = one 64 x 32 quadrant of the wave's 128 x 64 output (16 x v_mfma_f32_16x16x32_bf16) and ONE
+//     16 KiB half-tile of DMA (2 x buffer_load_dwordx4 ... lds per lane).  A wave's rows / columns are split over BOTH halves of
+//     the A / B tile (rows 64*wr + [0,64) of each 128-row half) so that a half-tile is dead after ONE phase and can be refilled
+//     while the K-step is still being computed: order of reads  P1: B-half 0 (4 x b128, retired before the barrier by a
+//     counted lgkmcnt(8)) + A-half 0 (8),  P2: B-half 1 (4),  P3: A-half 1 (8),  P4: none; order of refills
+//     P1: A-half 1 of step k+1,  P2: B-half 0,  P3: A-half 0,  P4: B-half 1 of step k+2;
+//   * the DMA is never drained inside the loop: one s_waitcnt vmcnt(6) per K-step (in P4, before its barrier) leaves the three
+//     youngest half-tiles in flight across the barriers; a buffer is read from the phase AFTER the wait that retires it;
+//   * the implicit-GEMM gather costs 5 VALU per DMA: every lane keeps a 32-bit byte offset of its output pixel and a bit mask of
+//     the window taps that fall inside the image; padding taps, rows beyond M, channels beyond Cd and K-steps beyond the last
+//     one use an offset outside the buffer descriptor, for which the hardware writes zeros (no zero page, no branches);
+//   * LDS rows are 128 bytes (64 bf16) with the 16-byte slot XOR-ed by (row>>1)&7 on the DMA source side and on the read side:
+//     the 16-lane groups of ds_read_b128 hit 16 different slots of the 256-byte bank row for the 16x16x32 operand layout.
+// Epilogue as in conv_epilogue.h (transposed bf16 image, ds_read_b64_tr_b16, 16-byte stores, BatchNorm sums), written for the
+// 16x16 accumulator layout.
+#include <stdlib.h>
+#include <type_traits>
+#include "dy_common.h"
+#include "conv_epilogue.h"
+#include "../../include/dedark_yolo.h"
+
+namespace v4 {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 128 * 128;                     // one half-tile: 128 rows x 64 bf16
+constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF, BUF = 4 * HALF;
+constexpr unsigned A_OOB = 0x80000000u;             // > any source extent (checked by the dispatcher: <= 2 GiB)
+constexpr unsigned B_ROW_OOB = 0x40000000u;         // weight extent <= 1 GiB: row-invalid + any k offset stays out of range
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct P {
+  const char* src;
+  const char* w;
+  char* dst;
+  unsigned src_bytes, w_bytes;
+  long src_ld, dst_ld, dst_row, dst_img;
+  int Hs, Ws, Cs, Hd, Wd, Cd;
+  int stride;
+  int KH, KW;
+  int dh0, dhs, dw0, dws;        // window tap (th, tw) reads source pixel (oh*stride + dh0 + dhs*th, ow*stride + dw0 + dws*tw)
+  int kh0, khs, kw0, kws, KWf;   // ... and weight tap (kh0 + khs*th, kw0 + kws*tw) of a KHf x KWf pack
+  long w_row;                    // elements per output-channel row of the weight pack
+  const float* scale;
+  const float* shift;
+  int act;
+  double* stats;
+  int accumulate;
+  long M;
+  int nk;                        // K-steps = KH*KW*Cs/64
+  int tiles_n, nblk;
+};
+
+__device__ inline int xcd_remap(int bid, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ inline long dst_offset(const P& p, long m) {
+  if (p.dst_row == 0) return m * p.dst_ld;
+  const long HWd = (long)p.Hd * p.Wd;
+  const long img = m / HWd;
+  const int rem = (int)(m - img * HWd);
+  const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+  return img * p.dst_img + (long)oh * p.dst_row + (long)ow * p.dst_ld;
+}
+
+// ABL: compile-time ablation mask for tools/v4_diag (the library only instantiates ABL = 0): 1 no DMA inside the loop, 2 no MFMA,
+// 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores.
+template <int ABL>
+__global__ __launch_bounds__(512) void conv_kernel(const P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // ---- DMA bookkeeping: instruction j of this wave fills rows 8*(wave + 8j) .. +7 of a half-tile; lane -> (row, 16-byte slot)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int chunk = slot ^ ((4 * wave + (lane >> 4)) & 7);      // logical 16-byte chunk of the row this lane fetches
+  unsigned a_off[4], a_mask[4], b_off[4];                        // index = 2 * half + j
+  {
+    const long HWd = (long)p.Hd * p.Wd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
+      const long m = m0 + r;
+      const bool ok = m < p.M;
+      const long mm = ok ? m : 0;
+      const int img = (int)(mm / HWd);
+      const int rem = (int)(mm - (long)img * HWd);
+      const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+      const int sh0 = oh * p.stride, sw0 = ow * p.stride;
+      a_off[i] = (unsigned)((((long)img * p.Hs + sh0) * p.Ws + sw0) * p.src_ld * 2 + chunk * 16);
+      unsigned mk = 0;
+      int bit = 0;
+      for (int th = 0; th < p.KH; ++th) {
+        const int sh = sh0 + p.dh0 + p.dhs * th;
+        for (int tw = 0; tw < p.KW; ++tw, ++bit) {
+          const int sw = sw0 + p.dw0 + p.dws * tw;
+          if (ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws) mk |= 1u << bit;
+        }
+      }
+      a_mask[i] = mk;
+      const int n = n0 + 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
+      b_off[i] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
+    }
+  }
+  // K-step whose half-tiles are being issued (all wave-uniform)
+  int sk = 0, s_th = 0, s_tw = 0, s_ci = 0, s_bit = 0;
+  int a_koff = (p.dh0 * p.Ws + p.dw0) * (int)p.src_ld * 2;
+  unsigned b_koff = (unsigned)(((long)(p.kh0 * p.KWf + p.kw0)) * p.Cs * 2);
+  auto advance = [&]() {
+    ++sk;
+    s_ci += BK;
+    a_koff += BK * 2;
+    b_koff += BK * 2;
+    if (s_ci >= p.Cs) {
+      s_ci = 0;
+      ++s_bit;
+      if (++s_tw == p.KW) { s_tw = 0; ++s_th; }
+      a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2;
+      b_koff = (unsigned)(((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs * 2);
+    }
+    if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a buffer nobody reads again)
+      s_bit = 31;
+      b_koff = 0x80000000u;
+    }
+  };
+  if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
+  bool in_loop = false;
+  auto stage_a = [&](int buf, int h) {
+    if ((ABL & 1) && in_loop) return;
+    if (ABL & 16) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = 2 * h + j;
+      const unsigned v = ((a_mask[i] >> s_bit) & 1u) ? a_off[i] + (unsigned)a_koff : A_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_A1 : OFF_A0) + (wave + 8 * j) * 1024), 16,
+                                               (int)v, 0, 0, 0);
+    }
+  };
+  auto stage_b = [&](int buf, int h) {
+    if ((ABL & 1) && in_loop) return;
+    if (ABL & 32) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = 2 * h + j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_B1 : OFF_B0) + (wave + 8 * j) * 1024), 16,
+                                               (int)(b_off[i] + b_koff), 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses (16x16x32: lane = row (lane&15), k chunk (lane>>4) of a 32-deep block)
+  const int fr = lane & 15, fq = lane >> 4, key = (fr >> 1) & 7;
+  const int off0 = ((((key >> 2) << 2) | ((fq ^ key) & 3)) << 4);
+  const int a_rd = (64 * wr + fr) * 128 + off0;          // + half base + 2048 * m-block ; k block 1: ^ 64
+  const int b_rd = (32 * wc + fr) * 128 + off0;
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 afr[4][2], bfr[2][2][2];
+
+  auto rd = [&](int byte) {
+    if (ABL & 4) return u32x4{(unsigned)byte, 1u, 2u, 3u};
+    return *reinterpret_cast<const u32x4*>(smem + byte);
+  };
+  auto read_a = [&](int buf, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      afr[i][0] = rd(buf * BUF + (h ? OFF_A1 : OFF_A0) + a_rd + 2048 * i);
+      afr[i][1] = rd(buf * BUF + (h ? OFF_A1 : OFF_A0) + (a_rd ^ 64) + 2048 * i);
+    }
+  };
+  auto read_b = [&](int buf, int h) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bfr[h][j][0] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + b_rd + 2048 * j);
+      bfr[h][j][1] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + (b_rd ^ 64) + 2048 * j);
+    }
+  };
+  auto mma = [&](int ah, int bh) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[bh][j][0])); asm volatile("" ::"v"(bfr[bh][j][1])); }
+      return;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[i][kb]),
+                                                                       __builtin_bit_cast(bf16x8, bfr[bh][j][kb]), acc[ah][bh][i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-step 0 complete + three half-tiles of K-step 1 in flight
+  stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
+  advance();
+  stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!(ABL & 8) && wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+  in_loop = true;
+
+  auto kstep = [&](auto bufc) {
+    constexpr int b = decltype(bufc)::value;
+    // P1
+    read_b(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_a(b ^ 1, 1);
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B reads (issued first) are back: B-half 0 may be refilled in P2
+    __builtin_amdgcn_s_barrier();
+    mma(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // P2
+    read_b(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_b(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // P3
+    read_a(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_a(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // P4
+    stage_b(b, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // everything but the three youngest half-tiles: K-step k+1 is complete
+    __builtin_amdgcn_s_barrier();
+    mma(1, 0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int kt = 0; kt < p.nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{});
+    if (kt + 1 < p.nk) kstep(std::integral_constant<int, 1>{});
+  }
+  if (!(ABL & 8) && wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero fills of the steps beyond the last one have landed
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: transposed bf16 image [col][row] (pitch 520 B) -> ds_read_b64_tr_b16 -> 16-byte stores
+  constexpr int PT = dy_epi::pitch<BM>();
+  const int cl = lane & 15, g = lane >> 4;
+  float csum[2][2], csq[2][2];
+#pragma unroll
+  for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 128 * bh + 32 * wc + 16 * j + cl;
+      const int n = n0 + col;
+      const bool nok = n < p.Cd;
+      const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+      const float sf = (nok && p.shift) ? p.shift[n] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row0 = 128 * ah + 64 * wr + 16 * i + 4 * g;
+          const long mrem = p.M - (m0 + row0);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[ah][bh][i][j][e];
+            if (nok && e < mrem) {
+              s1 += a;
+              s2 += a * a;
+            }
+            float u = a * sc + sf;
+            if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
+            else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
+            v[e] = u;
+          }
+          uint2 w2 = {dy_epi::pack2(v[0], v[1]), dy_epi::pack2(v[2], v[3])};
+          *reinterpret_cast<uint2*>(smem + col * PT + row0 * 2) = w2;
+        }
+      csum[bh][j] = s1;
+      csq[bh][j] = s2;
+    }
+  __syncthreads();
+  if (!(ABL & 64))
+  dy_epi::store_image<BM, BN, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
+                                 [&](long m) { return dst_offset(p, m); });
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);        // [2 (wr)][BN][2]
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float s1 = csum[bh][j], s2 = csq[bh][j];
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) {
+          const int col = 128 * bh + 32 * wc + 16 * j + cl;
+          red[(wr * BN + col) * 2] = s1;
+          red[(wr * BN + col) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.Cd) {
+        const float s1 = red[tid * 2] + red[(BN + tid) * 2];
+        const float s2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
+        atomic_add_f64(st + n, (double)s1);
+        atomic_add_f64(st + p.Cd + n, (double)s2);
+      }
+    }
+  }
+}
+
+}  // namespace v4
+
+// 256 x 256 tiles, one block per CU: worth it when the tiles fill the chip and are not mostly channel padding.
+#ifdef DY_V4_DIAG_BUILD
+static
+#endif
+bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode) {
+  static const bool off = getenv("DY_NO_CONV_V4") != nullptr;
+  if (off || d->dtype != DY_BF16) return false;
+  const long M = (long)d->N * d->Hd * d->Wd;
+  const long tn = (d->Cd + 255) / 256;
+  if (!(d->Cs % 64 == 0 && d->Cd >= 192 && tn * 256 * 4 <= (long)d->Cd * 5 && d->KH * d->KW <= 25)) return false;
+  if (((M + 255) / 256) * tn < 192) return false;
+  if (mode == 1 && d->stride != 1) return false;
+  if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0) return false;
+  const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
+  const long w_row = d->KHf > 0 ? (long)d->KHf * d->KWf * d->Cs : (long)d->KH * d->KW * d->Cs;
+  const long w_bytes = (long)d->Cd * w_row * 2;
+  return src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL;
+}
+
+template <int ABL>
+static int v4_launch(const dy_conv_desc* d, int mode, void* stream) {
+  v4::P p;
+  p.src = (const char*)d->src; p.w = (const char*)d->w; p.dst = (char*)d->dst;
+  p.src_ld = d->src_ld; p.dst_ld = d->dst_ld;
+  p.src_bytes = (unsigned)((((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2);
+  p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
+  p.KH = d->KH; p.KW = d->KW;
+  if (mode == 0) {
+    p.stride = d->stride; p.dh0 = -d->pad; p.dhs = d->dil; p.dw0 = -d->pad; p.dws = d->dil;
+  } else {               // stride-1 data gradient: dx[h] += dz[h + pad - kh*dil] * w[kh]
+    p.stride = 1; p.dh0 = d->pad; p.dhs = -d->dil; p.dw0 = d->pad; p.dws = -d->dil;
+  }
+  if (d->KHf > 0) {
+    p.kh0 = d->kh0; p.khs = d->kh_step; p.kw0 = d->kw0; p.kws = d->kw_step; p.KWf = d->KWf;
+    p.w_row = (long)d->KHf * d->KWf * d->Cs;
+  } else {
+    p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = d->KW;
+    p.w_row = (long)d->KH * d->KW * d->Cs;
+  }
+  p.w_bytes = (unsigned)((long)d->Cd * p.w_row * 2);
+  p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
+  p.M = (long)d->N * d->Hd * d->Wd;
+  p.nk = d->KH * d->KW * d->Cs / v4::BK;
+  p.dst_row = d->dst_row_stride;
+  p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
+  p.tiles_n = dy_cdiv(d->Cd, v4::BN);
+  p.nblk = dy_cdiv(p.M, v4::BM) * p.tiles_n;
+  constexpr int RING = 2 * v4::BUF, EPI = dy_epi::image_bytes<v4::BM, v4::BN>();
+  constexpr int SHMEM = RING > EPI ? RING : EPI;
+  static_assert(SHMEM <= 160 * 1024, "LDS budget");
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4::conv_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e != hipSuccess) {
+      dy_set_error("conv_v4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 3;
+    }
+    configured = true;
+  }
+  dy_note_kernel("v4::conv_kernel");
+  v4::conv_kernel<ABL><<<p.nblk, 512, SHMEM, (hipStream_t)stream>>>(p);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+#ifndef DY_V4_DIAG_BUILD
+int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream) { return v4_launch<0>(d, mode, stream); }
+#endif

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // ---- error plumbing (C-ABI returns int, message via dy_last_error) -------------------------------------------
 extern "C" const char* dy_last_error(void);
 void dy_set_error(const char* fmt, ...);
+void dy_note_kernel(const char* name);   // kernel symbol of the launch (error.cpp: dy_last_kernel)
 
 #define DY_CHECK(cond, ...)                      \
   do {                                           \

@@ -29,6 +29,10 @@ extern "C" {
 
 const char* dy_last_error(void);
 int dy_version(void);
+/* Profiling aid: symbol of the GPU kernel launched by the last call on this thread ("" if the entry reports none); bench.py
+ * attaches its per-kernel roofline to it.  dy_clear_last_kernel resets it. */
+const char* dy_last_kernel(void);
+void dy_clear_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------ convolution
  * Replaces nn.Conv2d inside Conv (U/nn/modules/conv.py:38-55), add_conv (U/nn/modules/block.py:24-45),
