@@ -103,6 +103,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dy_last_error.restype = C.c_char_p
         L.dy_last_error.argtypes = []
+        L.dy_last_kernel.restype = C.c_char_p
+        L.dy_last_kernel.argtypes = []
+        L.dy_clear_last_kernel.restype = None
+        L.dy_clear_last_kernel.argtypes = []
         for name, sig in _SIGS.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
             fn.argtypes = sig
@@ -112,10 +116,10 @@ def lib():
 
 
 def exported_symbols():
-    return ["dy_last_error"] + list(_SIGS)
+    return ["dy_last_error", "dy_last_kernel", "dy_clear_last_kernel"] + list(_SIGS)
 
 
-_prof = None          # list of (name, start_event, end_event, meta) while bench.py's per-kernel timing is active
+_prof = None          # list of (name, start_event, end_event, meta, kernel symbol) while bench.py's per-kernel timing is active
 _next_meta = None
 _UNTIMED = frozenset(["dy_stream_fork"])        # stream plumbing: events around it would time the wait, not a kernel
 
@@ -128,10 +132,12 @@ def call(name, *args):
     else:
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L.dy_clear_last_kernel()
         e0.record()                      # kernels are launched on torch's current stream, so these events bracket them
         rc = getattr(L, name)(*args)
         e1.record()
-        _prof.append((name, e0, e1, _next_meta))
+        kern = L.dy_last_kernel().decode()          # GPU kernel symbol the entry launched ("" = the entry does not report one)
+        _prof.append((name, e0, e1, _next_meta, kern))
         _next_meta = None
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {L.dy_last_error().decode()}")

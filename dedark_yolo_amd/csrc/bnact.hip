@@ -375,6 +375,7 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   const size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+  dy_note_kernel("bn_act_fwd_kernel");
 #define FWD(T_, U_) bn_act_fwd_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
                                                                     (T_*)y, y_ld, pixels, C, g.cgb, g.rows)
   if (dtype == DY_F32) { if (big) FWD(float, 4); else FWD(float, 2); }
@@ -395,6 +396,7 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   const Geo g = geometry(pixels, C, ve, 1);
   size_t shm = 6 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  dy_note_kernel("bn_act_bwd_reduce_kernel");
   if (dtype == DY_F32)
     bn_act_bwd_reduce_kernel<float, 2><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
                                                                 invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
@@ -419,6 +421,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   const size_t shm = 7 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+  dy_note_kernel("bn_act_bwd_apply_kernel");
 #define APPLY(T_, U_) bn_act_bwd_apply_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)dy, dy_ld, (const T_*)z, z_ld, scale, shift, mean, invstd, \
                                                                             gamma, act, has_bn, sums, (T_*)dz, dz_ld, dgamma, dbeta, pixels, \
                                                                             pixels > 0 ? pixels : 1, C, g.cgb, g.rows)

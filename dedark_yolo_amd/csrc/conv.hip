@@ -850,6 +850,7 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* class
       p.nblk = (int)acc;
     }
   };
+  dy_note_kernel(d->Cd <= 32 ? "conv_igemm_kernel<BN=32>" : (d->Cd <= 64 ? "conv_igemm_kernel<BN=64>" : "conv_igemm_kernel<BN=128>"));
   if (d->Cd <= 32) {
     blocks(32);
     conv_igemm_kernel<T, BM, 32, 4, 1, MODE><<<p.nblk, NTHREADS, 0, st>>>(p);
@@ -893,6 +894,7 @@ int launch_thin(const dy_conv_desc* d, int mode, hipStream_t st, const dy_conv_d
     }
     p.nblk = (int)acc;
   }
+  dy_note_kernel("conv_thin_kernel");
 #define THIN(C_, M_) conv_thin_kernel<C_, M_><<<p.nblk, NTHREADS, 0, st>>>(p)
   const int c16 = d->Cs / 16;
   if (mode == 0) { if (c16 == 1) THIN(1, 0); else if (c16 == 2) THIN(2, 0); else THIN(3, 0); }
@@ -1056,6 +1058,7 @@ int launch_wgrad(WgP p, float* scratch, long scratch_elems, float* g_oihw, int C
   p.chunk = chunk;
   p.part = scratch;
   dim3 grid(tiles, (unsigned)splits);
+  dy_note_kernel("conv_wgrad_kernel+wgrad_reduce_kernel");
 #define WG(BM_, BN_, WM_, WN_) conv_wgrad_kernel<T, BM_, BN_, WM_, WN_><<<grid, NTHREADS, 0, st>>>(p)
   if (bm == 128 && bn == 128) WG(128, 128, 2, 2);
   else if (bm == 64 && bn == 128) WG(64, 128, 1, 4);

@@ -151,6 +151,7 @@ int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
   const long quads = (long)d->N * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
   const unsigned grid = (unsigned)((quads + 255) / 256);
   const int nci = d->dst_valid_channels > 0 && d->dst_valid_channels <= 4 ? 4 : 8;
+  dy_note_kernel("dgrad3x3s2_small_kernel");
 #define GO(NCI)                                                                                                              \
   dgrad3x3s2_small_kernel<CS, NCI><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const uint32_t*)d->w, (bf16_t*)d->dst, \
                                                          d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate,        \
@@ -183,6 +184,7 @@ int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream) {
   if (thin_eligible(d)) {
     const long M = (long)d->N * d->Hd * d->Wd;
     const long threads = (M + THIN_PX - 1) / THIN_PX * (d->Cd / 8);
+    dy_note_kernel("dgrad1x1_thin_kernel");
     dgrad1x1_thin_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const bf16_t*)d->w,
                                                                            (bf16_t*)d->dst, d->dst_ld, M, d->Cd, d->accumulate);
     DY_LAUNCH_CHECK();

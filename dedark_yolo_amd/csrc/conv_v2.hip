@@ -327,6 +327,9 @@ int launch(P& p, hipStream_t st) {
     }
     p.nblk = (int)acc;
   }
+  static char name[64];
+  if (!name[0]) snprintf(name, sizeof(name), "v2::conv_kernel<%d, %d, %d, %s, %d>", BM, BN, MODE, SMALLC ? "true" : "false", NSTAGE);
+  dy_note_kernel(name);
   conv_kernel<BM, BN, MODE, SMALLC, NSTAGE><<<p.nblk, BM * 2, SHMEM, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;

@@ -314,6 +314,7 @@ int launch(P& p, hipStream_t st) {
   }
   p.tiles_n = dy_cdiv(p.Cd, BN);
   p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
+  dy_note_kernel(BN == 128 ? (MODE ? "v3::conv3x3_kernel<128, 1>" : "v3::conv3x3_kernel<128, 0>") : (MODE ? "v3::conv3x3_kernel<64, 1>" : "v3::conv3x3_kernel<64, 0>"));
   conv3x3_kernel<BN, MODE><<<p.nblk, NT, shm, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;

@@ -335,6 +335,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   splits = (p.M + chunk - 1) / chunk;
   p.chunk = chunk;
   hipStream_t st = (hipStream_t)stream;
+  dy_note_kernel(exp_mode == 2 ? "wg2::wgrad_kernel<256, 256, 2>+reduce_kernel" : (exp_mode == 0 ? "wg2::wgrad_kernel<128, 128, 2>+reduce_kernel" : "wg2::wgrad_kernel<256, 128>+reduce_kernel"));
   if (exp_mode == 1) wgrad_kernel<256, 128, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
   else if (exp_mode == 2) wgrad_kernel<256, 256, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
   else if (exp_mode == 4) wgrad_kernel<256, 128, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);

@@ -242,6 +242,7 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
     configured |= bit;
   }
   hipStream_t st = (hipStream_t)stream;
+  dy_note_kernel(Cin_pad == 64 ? "wg3::wgrad_kernel<64>+reduce_kernel" : "wg3::wgrad_kernel<128>+reduce_kernel");
   if (Cin_pad == 64) wgrad_kernel<64><<<dim3(nblk, ny), 384, shmem, st>>>(p);
   else wgrad_kernel<128><<<dim3(nblk, ny), 768, shmem, st>>>(p);
   DY_LAUNCH_CHECK();

@@ -178,6 +178,10 @@ class DevicePrefetcher:
         except StopIteration:
             self.nxt = None
             return
+        bi = b.get("batch_idx")
+        if "n_max" not in b and torch.is_tensor(bi) and not bi.is_cuda and torch.is_tensor(b.get("img")):
+            from ..utils.loss import n_max_of
+            b = dict(b, n_max=n_max_of(bi, int(b["img"].shape[0])))       # host-side bincount: no device sync in the criterion
         with torch.cuda.stream(self.stream):
             self.nxt = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) and not v.is_cuda else v) for k, v in b.items()}
 
@@ -267,6 +271,10 @@ class DetectionTrainer:
         img = batch["img"]
         if img.dtype != torch.uint8:
             raise RuntimeError("preprocess_batch expects the dataloader's uint8 image tensor")
+        bi = batch.get("batch_idx")
+        if "n_max" not in batch and torch.is_tensor(bi) and not bi.is_cuda:
+            from ..utils.loss import n_max_of
+            batch["n_max"] = n_max_of(bi, int(img.shape[0]))
         img = img.to(self.device, non_blocking=True).contiguous()
         n = img.numel()
         out = torch.empty(img.shape, dtype=torch.float32, device=self.device)

@@ -16,15 +16,29 @@ from ..ops import ld_of, ptr, stream
 REG_MAX = 16
 
 
-def _n_max_of(batch_idx, bsz):
-    """Largest number of boxes in one image (host value). batch_idx normally lives on the CPU (dataloader); a GPU tensor
-    costs one sync, like `counts.max()` in the reference (loss.py:130-132)."""
+_n_max_cache = {}
+
+
+def n_max_of(batch_idx, bsz):
+    """Largest number of boxes in one image (host value), the reference's `counts.max()` (loss.py:130-132).  batch_idx normally
+    lives on the CPU (dataloader), where this is a host-side bincount; DevicePrefetcher / preprocess_batch compute it BEFORE the
+    upload and hand it over as batch['n_max'].  A batch_idx that only exists on the device costs one synchronisation the first
+    time that tensor is seen (cached per storage + version: a resident batch that is reused stays sync-free afterwards)."""
     if batch_idx.numel() == 0:
         return 0
     bi = batch_idx.detach().view(-1)
-    if bi.is_cuda:
-        return int(torch.bincount(bi.long(), minlength=bsz).max().item())
-    return int(torch.bincount(bi.long(), minlength=bsz).max())
+    if not bi.is_cuda:
+        return int(torch.bincount(bi.long(), minlength=bsz).max())
+    key = (bi.data_ptr(), bi.numel(), bi._version, bsz)
+    hit = _n_max_cache.get(key)
+    if hit is None:
+        if len(_n_max_cache) > 64:
+            _n_max_cache.clear()
+        hit = _n_max_cache[key] = int(torch.bincount(bi.long(), minlength=bsz).max().item())
+    return hit
+
+
+_n_max_of = n_max_of
 
 
 class _Assignment:

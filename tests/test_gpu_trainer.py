@@ -127,7 +127,7 @@ def test_train_loop_steps_optimizer_every_accumulate_batches():
     tr = _tiny_trainer("SGD", batch=32, warmup_epochs=0.0, epochs=1, imgsz=64)
     batches = [bench.synth_batch(40 + i, 2, 64, 20, "cuda") for i in range(4)]
     for b in batches:
-        b.pop("gamma"), b.pop("n_max")
+        b.pop("gamma"), b.pop("n_max", None)
     before = tr.updates
     hist = tr.train(batches, epochs=1)
     assert tr.updates - before == 2 and len(hist) == 1 and all(np.isfinite(hist[0]))
@@ -146,7 +146,7 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
     try:
         b = bench.synth_batch(77, 4, 96, 20, "cuda")
         tr.args.dark_param = b.pop("gamma")
-        b.pop("n_max")
+        b.pop("n_max", None)
         losses = []
         for _ in range(120):
             loss, _ = tr.train_step(dict(b), [0.01] * 3, 0.9)
@@ -173,7 +173,7 @@ def test_side_streams_do_not_change_the_step():
         for i in range(3):
             b = bench.synth_batch(50 + i, 4, 96, 20, "cuda")
             tr.args.dark_param = b.pop("gamma")
-            b.pop("n_max")
+            b.pop("n_max", None)
             loss, _ = tr.train_step(b, [0.01] * 3, 0.9)
             losses.append(float(loss))
         torch.cuda.synchronize()
@@ -203,7 +203,7 @@ def test_checkpoint_save_and_resume(tmp_path):
     for i in range(3):
         b = bench.synth_batch(60 + i, 4, 96, 20, "cuda")
         tr.args.dark_param = b.pop("gamma")
-        b.pop("n_max")
+        b.pop("n_max", None)
         tr.train_step(b, [0.01] * 3, 0.9)
     last = tr.save_model(str(tmp_path), epoch=4, fitness=0.25)
     ck = torch.load(last, map_location="cpu", weights_only=False)
@@ -221,7 +221,7 @@ def test_checkpoint_save_and_resume(tmp_path):
     assert torch.equal(tr2.flat.m, tr.flat.m) and tr2.updates == tr.updates and tr2.step_count == tr.step_count
     b = bench.synth_batch(70, 4, 96, 20, "cuda")
     tr2.args.dark_param = b.pop("gamma")
-    b.pop("n_max")
+    b.pop("n_max", None)
     loss, _ = tr2.train_step(b, [0.01] * 3, 0.9)
     assert np.isfinite(float(loss))
     y = YOLO(last)                                          # the predictor reads the same file (weights_only load)
@@ -239,7 +239,7 @@ def test_train_loop_uploads_host_batches_through_the_prefetcher():
         tr = _tiny_trainer("SGD", batch=64, warmup_epochs=0.0, epochs=1, imgsz=64)
         batches = [bench.synth_batch(90 + i, 2, 64, 20, "cuda") for i in range(5)]
         for b in batches:
-            b.pop("gamma"), b.pop("n_max")
+            b.pop("gamma"), b.pop("n_max", None)
         if host:
             batches = [{k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
         return tr.train(batches, epochs=2)

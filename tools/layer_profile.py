@@ -46,7 +46,7 @@ def main():
     torch.cuda.synchronize()
     rec, _C._prof = _C._prof, None
     agg = {}
-    for name, e0, e1, meta in rec:
+    for name, e0, e1, meta, _kern in rec:
         key = (name, (meta or {}).get("shape", ""))
         v = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
         v[0] += e0.elapsed_time(e1)
