@@ -39,6 +39,11 @@ bool dy_dense_wgrad_eligible(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int
 int dy_dense_wgrad_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout, int Cin,
                           float* g_oihw, int dtype, void* stream);
 // band weight gradient for the 64-channel 3x3 layers (wgrad_v3.hip)
+bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, int N, int Hi, int Wi, int Ho, int Wo, long x_ld,
+                          long dz_ld, long scratch_elems);
+int dy_wgrad_v4_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
+                       int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
+                       long scratch_elems, float* g_oihw, void* stream);
 bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
                           long x_ld, long dz_ld, long scratch_elems);
 int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
@@ -1091,6 +1096,9 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
     return dy_dense_wgrad_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout, Cin, g_oihw, dtype, stream);
   if (dy_wgrad_v3_eligible(dtype, Cin_pad, Cout_pad, KH, KW, stride, pad, dil, N, Hi, Wi, x_ld, dz_ld, scratch_elems))
     return dy_wgrad_v3_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout_pad, Cout, Cin, scratch, scratch_elems, g_oihw, stream);
+  if (dy_wgrad_v4_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, N, Hi, Wi, Ho, Wo, x_ld, dz_ld, scratch_elems))
+    return dy_wgrad_v4_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
+                              scratch_elems, g_oihw, stream);
   if (dy_wgrad_v2_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, x_ld, dz_ld))
     return dy_wgrad_v2_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
                               scratch_elems, g_oihw, stream);

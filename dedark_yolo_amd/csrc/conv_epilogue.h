@@ -32,8 +32,12 @@ __device__ inline void store_image(const char* smem, int lane, int wave, long m0
   constexpr int PT = pitch<BM>();
   constexpr int UP = BM / 16, UC = BN / 32;
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int u = wave; u < UP * UC; u += NW) {
-    const int pt = u / UC, ct = u - pt * UC;
+  // a wave walks the channel tiles of ITS pixel tiles: consecutive store instructions of one wave complete the 128-byte lines
+  // of the same 16 pixels (adjacent 64-byte pieces), instead of eight waves each writing one piece of every line
+  static_assert(UP % NW == 0, "pixel tiles per wave");
+#pragma unroll 2
+  for (int u = 0; u < (UP / NW) * UC; ++u) {
+    const int pt = wave + NW * (u / UC), ct = u % UC;
     const int cb = ct * 32 + 8 * g;                // first channel of this lane's 8-channel vector
     const char* base = smem + (cb + tq) * PT + (pt * 16 + 4 * tp) * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
@@ -61,6 +65,56 @@ __device__ inline void store_image(const char* smem, int lane, int wave, long m0
       } else {                                     // ragged channel tail (never happens for padded views)
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
         for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+      }
+    }
+  }
+}
+
+// ---- Row-major variant for kernels whose accumulators hold CHANNELS in the registers and PIXELS on the lanes (the conv_v4
+// kernels compute the transposed product: MFMA rows = output channels).  A lane's 4 consecutive channels of one pixel are one
+// ds_write_b64 into image[pixel][channel] (pitch BN*2 + 8 bytes: 16 pixels x 8 bytes hit 32 different banks); the store phase
+// reads 16 bytes per lane (two ds_read_b64, conflict-free) so that each 16-lane quarter of a store instruction writes 256
+// CONTIGUOUS bytes of one pixel (the [col][row] image above gives 16 pixels x 64 bytes per instruction: a quarter-wave then touches
+// 16 different lines and the store phase ran at 1-2 TB/s chip-wide).
+template <int BN>
+constexpr int row_pitch() { return BN * 2 + 8; }
+
+template <int BM, int BN>
+constexpr int row_image_bytes() { return BM * row_pitch<BN>(); }
+
+template <int BM, int BN, int NW, typename OffFn>
+__device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, bf16_t* dst, OffFn off) {
+  constexpr int PT = row_pitch<BN>();
+  constexpr int ITERS = BM / 4 / NW;               // 4 pixels per wave instruction
+  const int pl = lane >> 4, chunk = lane & 15;
+#pragma unroll 2
+  for (int u = 0; u < ITERS; ++u) {
+    const int px = 4 * (wave + NW * u) + pl;
+    const long m = m0 + px;
+#pragma unroll
+    for (int h = 0; h < BN / 128; ++h) {
+      const int c = 128 * h + 8 * chunk;
+      const uint2 lo = *reinterpret_cast<const uint2*>(smem + px * PT + c * 2);
+      const uint2 hi = *reinterpret_cast<const uint2*>(smem + px * PT + c * 2 + 8);
+      const int n = n0 + c;
+      if (m < M && n < Cd) {
+        u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+        bf16_t* o = dst + off(m) + n;
+        if (n + 8 <= Cd) {
+          if (accumulate) {
+            float x[8], y[8];
+            ldvec<bf16_t>(o, x);
+            ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            stvec<bf16_t>(o, x);
+          } else {
+            *reinterpret_cast<u32x4*>(o) = v;
+          }
+        } else {
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+        }
       }
     }
   }

@@ -29,6 +29,7 @@ static void run(const char* what, dy_conv_desc& f, double flops, hipStream_t st,
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, Cc = argc > 2 ? atoi(argv[2]) : 256, HW = argc > 3 ? atoi(argv[3]) : 40, k = argc > 4 ? atoi(argv[4]) : 3;
+  // (the tile variant follows the channel count: 256 -> 256 x 256 tile, 128 -> 256 x 128 tile)
   const int pad = k / 2;
   const long nx = (long)B * HW * HW * Cc, nw = (long)Cc * k * k * Cc;
   std::vector<unsigned short> hx(nx), hw(nw);
