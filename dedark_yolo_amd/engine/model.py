@@ -29,10 +29,20 @@ class YOLO:
         self.overrides["model"] = cfg
 
     def _load(self, weights):
-        ck = torch.load(weights, map_location="cpu", weights_only=True)
-        cfg = ck.get("yaml") or ck.get("cfg")
-        self.model = DetectionModel(cfg, nc=ck.get("nc"))
-        self.model.load(ck["state_dict"])
+        """reference nn/tasks.py:592-630,674-707 (attempt_load_one_weight): `ckpt.get('ema') or ckpt['model']`, cast to fp32.  Reads
+        both this package's state_dict checkpoints and the reference's pickled-module last.pt / best.pt (utils/checkpoint.py)."""
+        from ..utils.checkpoint import load_checkpoint
+        ck = load_checkpoint(weights)
+        cfg = ck.yaml
+        if cfg is None:
+            raise RuntimeError(f"{weights}: the checkpoint carries no model yaml")
+        self.model = DetectionModel(cfg, nc=ck.nc)
+        n = self.model.load(ck.state_dict)
+        if n == 0:
+            raise RuntimeError(f"{weights}: no tensor of the checkpoint matches the graph of its yaml")
+        if isinstance(ck.names, dict) and len(ck.names) == len(self.model.names):
+            self.model.names = {int(k): str(v) for k, v in ck.names.items()}
+        self.ckpt = ck
         self.cfg = cfg
         self.overrides["model"] = cfg
 

@@ -373,9 +373,83 @@ def g_val():
     save("g6_match", det=det, lab=lab, correct=correct)
 
 
+# ------------------------------------------------------------------ G7: a checkpoint exactly as the reference trainer writes it
+def g_ckpt():
+    """last.pt of ultralytics/engine/trainer.py:408-433 for a tiny model: pickled half-precision DetectionModel objects under
+    'model' and 'ema' (different weights), train_args, counters.  Data only (tensors + class NAMES); the reader under test is
+    dedark_yolo_amd/utils/checkpoint.py, which must rebuild the state_dicts without the reference package."""
+    from copy import deepcopy
+    d = yaml_model_load("yolov8nori.yaml")
+    d["scales"]["t"] = [0.33, 0.0625, 1024]
+    d["scale"] = "t"
+    m = DetectionModel(d, ch=3, nc=4, verbose=False)
+    m.args = dict(box=7.5, cls=0.5, dfl=1.5, lrl=2.0, imgsz=64)
+    fill(m, 701)
+    ema = deepcopy(m)
+    fill(ema, 702)
+    ckpt = {"epoch": 3, "best_fitness": 0.4321, "model": deepcopy(m).half(), "ema": deepcopy(ema).half(), "updates": 77,
+            "optimizer": None, "train_args": dict(model="yolov8nori.yaml", imgsz=64, batch=2, lowlight_FLAG=True, dedark_FLAG=True),
+            "date": "2026-01-01T00:00:00", "version": "8.0.142"}
+    path = os.path.join(HERE, "g7_ref_last.pt")
+    torch.save(ckpt, path)
+    sd_m, sd_e = m.state_dict(), ema.state_dict()
+    keys = list(sd_m.keys())
+    save("g7_ckpt", n_keys=len(keys), key_first=np.array(keys[0]), key_last=np.array(keys[-1]),
+         sum_model=np.array([float(sd_m[k].half().float().double().sum()) for k in keys]),
+         sum_ema=np.array([float(sd_e[k].half().float().double().sum()) for k in keys]), keys=np.array(keys))
+    print(f"g7_ref_last.pt: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------ G8: preprocess_batch (tensor part) and the pre-NMS stage
+def g_pre():
+    """DetectionTrainer.preprocess_batch (models/yolo/detect/train.py:70-111), tensor part: img/255, x^dark_param, mse -- for the
+    three flag combinations.  The numpy dark-channel branch reads np.empty memory (train.py:65-67): its outputs (dedark_A, IcA) are
+    not captured.  Pre-NMS stage of non_max_suppression (utils/ops.py:196-259): torchvision.ops.nms is replaced by a recorder that
+    keeps what it is called with (boxes + class offsets, scores) and keeps everything, so the candidate filter, xywh2xyxy,
+    multi-label expansion, max_nms cap and the class offset are pinned; the greedy suppression itself stays unpinned."""
+    from ultralytics.models.yolo.detect.train import DetectionTrainer
+    g = np.random.default_rng(81)
+    img = T(g.integers(0, 256, (2, 3, 24, 32), dtype=np.uint8))
+    out = {}
+    for tag, low, ded in (("both", True, True), ("low", True, False), ("none", False, False)):
+        # (the numpy dark-channel helpers call cv2, which is absent: arithmetic-free stand-ins; their outputs are not captured)
+        me = SimpleNamespace(device=torch.device("cpu"), args=SimpleNamespace(dedark_FLAG=ded, lowlight_FLAG=low, dark_param=3.5),
+                             DarkChannel=lambda im: np.zeros(im.shape[:2]), AtmLight=lambda im, dk: np.zeros((1, 3)),
+                             DarkIcA=lambda im, A: np.zeros(im.shape[:2]))
+        b = DetectionTrainer.preprocess_batch(me, dict(img=img.clone()))
+        out[f"{tag}_img"], out[f"{tag}_clean"], out[f"{tag}_rec"] = b["img"], b["clean_img"], b["recovery_loss_batch"]
+    save("g8_preprocess", u8=img, dark_param=3.5, **out)
+
+    import torchvision
+    calls = []
+
+    def rec_nms(boxes, scores, iou):
+        calls.append((boxes.clone(), scores.clone(), float(iou)))
+        return torch.arange(boxes.shape[0])
+    torchvision.ops.nms = rec_nms
+    uops.torchvision = torchvision
+    nc, A, B = 5, 300, 2
+    pred = torch.zeros(B, 4 + nc, A)
+    pred[:, 0:2] = T(g.uniform(40, 600, (B, 2, A)).astype(np.float32))
+    pred[:, 2:4] = T(g.uniform(10, 200, (B, 2, A)).astype(np.float32))
+    pred[:, 4:] = T((g.random((B, nc, A)) ** 3).astype(np.float32))
+    arrs = dict(pred=pred)
+    for tag, kw in (("ml", dict(multi_label=True)), ("sl", dict(multi_label=False)), ("cap", dict(multi_label=True, max_nms=50)),
+                    ("agn", dict(multi_label=True, agnostic=True))):
+        calls.clear()
+        outs = uops.non_max_suppression(pred.clone(), conf_thres=0.3, iou_thres=0.6, max_det=1000, **kw)
+        for i, (bx, sc, iou) in enumerate(calls):
+            arrs[f"{tag}_boxes{i}"], arrs[f"{tag}_scores{i}"] = bx, sc
+        for i, o in enumerate(outs):
+            arrs[f"{tag}_out{i}"] = o
+        arrs[f"{tag}_ncalls"] = len(calls)
+    save("g9_prenms", **arrs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or None
-    todo = dict(frontend=g_frontend, blocks=g_blocks, models=g_models, assigner=g_assigner, small=g_small, val=g_val)
+    todo = dict(frontend=g_frontend, blocks=g_blocks, models=g_models, assigner=g_assigner, small=g_small, val=g_val, ckpt=g_ckpt,
+                pre=g_pre)
     for k, fn in todo.items():
         if not ONLY or k in ONLY:
             fn()

@@ -227,7 +227,8 @@ def test_checkpoint_save_and_resume(tmp_path):
     y = YOLO(last)                                          # the predictor reads the same file (weights_only load)
     sd = y.model.state_dict()
     k0 = next(k for k in sd if k.endswith("conv.weight"))
-    assert float((sd[k0].cpu() - ck["model"][k0].float()).abs().max()) == 0.0
+    assert float((sd[k0].cpu() - ck["ema"][k0].float()).abs().max()) == 0.0      # EMA weights first (nn/tasks.py:640,682)
+    assert float((ck["ema"][k0].float() - ck["model"][k0].float()).abs().max()) > 0.0
 
 
 def test_train_loop_uploads_host_batches_through_the_prefetcher():
@@ -248,3 +249,36 @@ def test_train_loop_uploads_host_batches_through_the_prefetcher():
     # (two runs of the same ten optimizer steps differ at 1e-4..1e-3 relative: f64-atomic order + batch-2 BatchNorm; a batch that
     #  was consumed before its upload finished would be off by O(1))
     assert np.allclose(np.array(h), np.array(d), rtol=1e-2, atol=1e-5), (h, d)
+
+
+def test_yolo_reads_a_reference_checkpoint_and_predicts():
+    """YOLO('<reference last.pt>'): pickled reference modules -> state_dict -> HIP model; the EMA weights are the ones loaded
+    (nn/tasks.py:640,682) and the predictor runs on them."""
+    import os
+    from dedark_yolo_amd.engine.model import YOLO
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    y = YOLO(os.path.join(root, "tests", "golden", "g7_ref_last.pt"))
+    z = np.load(os.path.join(root, "tests", "golden", "g7_ckpt.npz"))
+    sd = y.model.state_dict()
+    keys = [str(k) for k in z["keys"]]
+    got = np.array([float(sd[k].double().sum()) for k in keys if not k.endswith("num_batches_tracked")])
+    want = np.array([s for k, s in zip(keys, z["sum_ema"]) if not k.endswith("num_batches_tracked")])
+    assert np.abs(got - want).max() == 0.0
+    y.model.cuda()
+    img = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (2, 3, 64, 64), dtype=np.uint8)).cuda()
+    res = y.predict(img, conf=0.001)
+    assert len(res) == 2 and all(r.boxes.data.shape[1] == 6 for r in res)
+
+
+def test_preprocess_batch_vs_reference_fixture():
+    """HIP preprocess kernel against the values captured from the reference's DetectionTrainer.preprocess_batch (g8_preprocess.npz)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "g8_preprocess.npz"))
+    tr = _tiny_trainer("SGD")
+    for tag, low, ded in (("both", True, True), ("low", True, False), ("none", False, False)):
+        tr.args.lowlight_FLAG, tr.args.dedark_FLAG, tr.args.dark_param = low, ded, float(z["dark_param"])
+        out = tr.preprocess_batch(dict(img=torch.from_numpy(z["u8"]).clone()))
+        assert float((out["img"].cpu() - torch.from_numpy(z[f"{tag}_img"])).abs().max()) <= 1e-6, tag
+        assert float((out["clean_img"].cpu() - torch.from_numpy(z[f"{tag}_clean"])).abs().max()) <= 1e-6, tag
+        assert abs(float(out["recovery_loss_batch"]) - float(z[f"{tag}_rec"])) <= 1e-6, tag

@@ -230,3 +230,26 @@ def test_predict_results_vs_oracle_nms():
         assert torch.allclose(got[:, :4], w[:, :4], rtol=1e-6, atol=1e-4), f"image {i}"
         assert r.boxes.xyxy.shape == (len(r), 4) and r.boxes.conf.shape == (len(r),) and r.boxes.cls.shape == (len(r),)
         assert float(r.boxes.xyxyn.max()) <= 1.0 + 1e-6 if len(r) else True
+
+
+def test_nms_candidate_stage_vs_reference_fixture():
+    """The part of non_max_suppression in front of torchvision.ops.nms, captured from the reference (g9_prenms.npz: the nms call
+    was replaced by a recorder that keeps every box).  With iou_thres = 1 nothing is suppressed here either, so the HIP pipeline
+    must return exactly the reference's candidate rows (as a set: the reference keeps candidate order, the kernel score order)."""
+    import os
+    import numpy as np
+    from dedark_yolo_amd.utils.ops import nms_batched
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "g9_prenms.npz"))
+    pred = torch.from_numpy(z["pred"]).cuda()
+
+    def rows(t):
+        a = t.numpy() if isinstance(t, torch.Tensor) else t
+        return a[np.lexsort(a.T[::-1])]
+    for tag, ml, agn, max_nms in (("ml", True, False, 30000), ("sl", False, False, 30000), ("cap", True, False, 50), ("agn", True, True, 30000)):
+        out, cnt = nms_batched(pred, 0.3, 1.0, ml, agn, 2000, max_nms, 7680)
+        torch.cuda.synchronize()
+        for i in range(2):
+            want = z[f"{tag}_out{i}"]
+            assert int(cnt[i]) == want.shape[0], (tag, i, int(cnt[i]), want.shape[0])
+            assert np.array_equal(rows(out[i, :want.shape[0]].cpu()), rows(want)), (tag, i)

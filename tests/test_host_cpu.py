@@ -70,13 +70,13 @@ def test_library_exports_every_declared_symbol():
     assert len(decls) > 30
     table = dict(_C._SIGS)
     for name, n in decls.items():
-        if name == "dy_last_error":
+        if name in ("dy_last_error", "dy_last_kernel"):     # const char* accessors, bound by hand in _C.lib()
             continue
         assert name in table, f"{name} declared in the header but missing from the ctypes table"
         assert len(table[name]) == n, f"{name}: header has {n} args, ctypes table {len(table[name])}"
     assert set(table) <= set(decls), set(table) - set(decls)
     lib = _C.lib()                       # raises if the .so is missing or a symbol is not exported
-    assert lib.dy_version() == 1
+    assert lib.dy_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True).stdout
     for name in decls:
         assert re.search(rf"\b{name}\b", out), f"{name} not exported"
@@ -149,3 +149,45 @@ def test_product_metrics_match_reference_goldens():
     assert torch.equal(match_predictions(g["det"], g["lab"], torch.linspace(0.5, 0.95, 10)), g["correct"].bool())
     s = gold("g5_small")
     close(M.box_iou(s["b1"][:8], s["b2"][:12]), s["pairwise"], 0, 1e-7, "box_iou")
+
+
+def test_reference_checkpoint_reader():
+    """tests/golden/g7_ref_last.pt was written by the reference's own classes exactly as trainer.save_model does
+    (engine/trainer.py:408-433: pickled half-precision DetectionModel objects under 'model' and 'ema').  The restricted unpickler
+    rebuilds both state_dicts without the reference package, 'ema' takes precedence (nn/tasks.py:640,682), DetectionModel.load takes it."""
+    import numpy as np
+    import torch
+    from dedark_yolo_amd.utils.checkpoint import load_checkpoint
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = load_checkpoint(os.path.join(root, "tests", "golden", "g7_ref_last.pt"))
+    z = np.load(os.path.join(root, "tests", "golden", "g7_ckpt.npz"))
+    keys = [str(k) for k in z["keys"]]
+    assert ck.source == "reference-pickle" and list(ck.state_dict) == keys and list(ck.model_sd) == keys
+    se = np.array([float(ck.state_dict[k].double().sum()) for k in keys])
+    sm = np.array([float(ck.model_sd[k].double().sum()) for k in keys])
+    assert np.abs(se - z["sum_ema"]).max() == 0.0 and np.abs(sm - z["sum_model"]).max() == 0.0
+    assert np.abs(z["sum_ema"] - z["sum_model"]).max() > 0.0            # the two really differ
+    assert (ck.epoch, ck.updates, ck.nc) == (3, 77, 4) and abs(ck.best_fitness - 0.4321) < 1e-12
+    assert ck.train_args["lowlight_FLAG"] is True and isinstance(ck.yaml, dict) and ck.yaml["scale"] == "t"
+    assert all(v.dtype == torch.float32 for v in ck.state_dict.values() if v.is_floating_point())
+    # the graph of the checkpoint's yaml builds here and takes every tensor
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    m = DetectionModel(ck.yaml, nc=ck.nc)
+    assert m.load(ck.state_dict) == len(keys)
+    sd = m.state_dict()
+    assert all(torch.equal(sd[k], ck.state_dict[k]) for k in keys if k in sd and not k.endswith("num_batches_tracked"))
+
+
+def test_checkpoint_reader_refuses_to_run_code(tmp_path):
+    """A pickle that names an arbitrary callable must come back as an inert record, never be called."""
+    import pickle
+    import torch
+    from dedark_yolo_amd.utils.checkpoint import load_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    f = tmp_path / "evil.pt"
+    torch.save(dict(model=dict(w=torch.zeros(1)), junk=Evil()), f)
+    ck = load_checkpoint(str(f))
+    assert not (tmp_path / "pwned").exists() and "w" in ck.state_dict

@@ -251,3 +251,37 @@ def test_match_predictions_golden():
     g = gold("g6_match")
     got = oval.match_predictions(g["det"], g["lab"], torch.linspace(0.5, 0.95, 10))
     assert torch.equal(got, g["correct"].bool())
+
+
+def test_preprocess_batch_golden():
+    """DetectionTrainer.preprocess_batch, tensor part (detect/train.py:70-111) captured from the reference for the three flag
+    combinations (g8_preprocess.npz)."""
+    from oracle import loss as oloss
+    g = gold("g8_preprocess")
+    for tag, low, ded in (("both", True, True), ("low", True, False), ("none", False, False)):
+        img, clean, rec = oloss.preprocess_batch(g["u8"], float(g["dark_param"]), low, ded)
+        close(img, g[f"{tag}_img"], 0, 1e-7, tag + " img")
+        close(clean, g[f"{tag}_clean"], 0, 1e-7, tag + " clean")
+        close(rec, g[f"{tag}_rec"], 1e-6, 1e-9, tag + " recovery")
+
+
+def test_pre_nms_stage_golden(monkeypatch):
+    """Everything non_max_suppression does BEFORE torchvision.ops.nms (utils/ops.py:196-259: candidate filter, xywh2xyxy,
+    multi-label expansion, max_nms cap, class offsets) captured from the reference with a recording stand-in for the nms call that
+    keeps every box (g9_prenms.npz); the oracle must hand ITS nms the same boxes / scores and produce the same rows."""
+    g = gold("g9_prenms")
+    calls = []
+
+    def rec(boxes, scores, thr):
+        calls.append((boxes.clone(), scores.clone()))
+        return torch.arange(boxes.shape[0])
+    monkeypatch.setattr(oval, "nms", rec)
+    for tag, kw in (("ml", dict(multi_label=True)), ("sl", dict(multi_label=False)), ("cap", dict(multi_label=True, max_nms=50)),
+                    ("agn", dict(multi_label=True, max_wh=0))):
+        calls.clear()
+        out = oval.non_max_suppression(g["pred"].clone(), 0.3, 0.6, max_det=1000, **kw)
+        assert len(calls) == int(g[f"{tag}_ncalls"]) == 2
+        for i in range(2):
+            assert torch.equal(calls[i][0], g[f"{tag}_boxes{i}"]), (tag, i, "boxes handed to nms")
+            assert torch.equal(calls[i][1], g[f"{tag}_scores{i}"]), (tag, i, "scores handed to nms")
+            assert torch.equal(out[i], g[f"{tag}_out{i}"]), (tag, i, "rows")
