@@ -74,6 +74,7 @@ _SIGS = {
     "dy_loss_prepare_targets": [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],
     "dy_loss_decode": [C.POINTER(DetMaps), vp, vp],
     "dy_tal_assign": [C.POINTER(DetMaps), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "dy_tal_assign_decoded": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],
     "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],
     "dy_loss_bwd": [C.POINTER(DetMaps), vp * 3, i64 * 3, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp],

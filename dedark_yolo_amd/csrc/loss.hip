@@ -22,6 +22,10 @@ struct Maps {
   int h[3], w[3], off[4];
   float stride[3];
   int B, nc, nl, A;
+  // decoded-input mode of the assigner (dy_tal_assign_decoded = TaskAlignedAssigner.forward's own arguments): class probabilities
+  // [B, A, nc] f32 and anchor points [A, 2] in pixels; the predicted boxes are then in pixels too.  Both null otherwise.
+  const float* dec_scores;
+  const float* dec_anchors;
 };
 
 __device__ inline void anchor_of(const Maps& m, int a, int& lvl, int& cell, float& ax, float& ay) {
@@ -124,12 +128,98 @@ __device__ inline void heap_adjust(float* hv, int* hi, int hole, int len, float 
   hv[hole] = v; hi[hole] = idx;
 }
 
+// ---- torch.topk on rows shorter than 64 * k takes std::nth_element (ATen TopKImpl.h: partial_sort only when k * 64 <= n), whose
+// treatment of equal values (the zero-metric anchors of a ground truth with fewer than 10 positive candidates) decides which of
+// them become positives.  What follows is libstdc++'s introselect on (value, index) pairs, statement for statement as documented in
+// <bits/stl_algo.h> / <bits/stl_heap.h> (__introselect, __unguarded_partition_pivot, __move_median_to_first, __unguarded_partition,
+// __insertion_sort, __heap_select), run by one thread on LDS copies of the row: the first k entries afterwards are torch's top-k.
+constexpr int SMALL_A = 64 * TOPK;                    // rows shorter than this take nth_element in torch
+
+__device__ inline void nth_swap(float* v, int* x, int a, int b) {
+  const float tv = v[a]; v[a] = v[b]; v[b] = tv;
+  const int tx = x[a]; x[a] = x[b]; x[b] = tx;
+}
+
+__device__ inline void nth_median_to_first(float* v, int* x, int result, int a, int b, int c) {
+  if (topk_comp(v[a], v[b])) {
+    if (topk_comp(v[b], v[c])) nth_swap(v, x, result, b);
+    else if (topk_comp(v[a], v[c])) nth_swap(v, x, result, c);
+    else nth_swap(v, x, result, a);
+  } else if (topk_comp(v[a], v[c])) nth_swap(v, x, result, a);
+  else if (topk_comp(v[b], v[c])) nth_swap(v, x, result, c);
+  else nth_swap(v, x, result, b);
+}
+
+__device__ inline int nth_partition(float* v, int* x, int first, int last, int pivot) {
+  while (true) {
+    while (topk_comp(v[first], v[pivot])) ++first;
+    --last;
+    while (topk_comp(v[pivot], v[last])) --last;
+    if (!(first < last)) return first;
+    nth_swap(v, x, first, last);
+    ++first;
+  }
+}
+
+__device__ inline void nth_insertion_sort(float* v, int* x, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    const float val = v[i];
+    const int idx = x[i];
+    if (topk_comp(val, v[first])) {
+      for (int j = i; j > first; --j) { v[j] = v[j - 1]; x[j] = x[j - 1]; }
+      v[first] = val; x[first] = idx;
+    } else {
+      int lastp = i, next = i - 1;
+      while (topk_comp(val, v[next])) { v[lastp] = v[next]; x[lastp] = x[next]; lastp = next; --next; }
+      v[lastp] = val; x[lastp] = idx;
+    }
+  }
+}
+
+// __heap_select(first, middle, last) on the sub-array starting at `first` (only reached when introselect runs out of depth)
+__device__ inline void nth_heap_select(float* v, int* x, int first, int middle, int last) {
+  const int len = middle - first;
+  if (len >= 2)
+    for (int parent = (len - 2) / 2; parent >= 0; --parent) heap_adjust(v + first, x + first, parent, len, v[first + parent], x[first + parent]);
+  for (int i = middle; i < last; ++i)
+    if (topk_comp(v[i], v[first])) {
+      const float val = v[i];
+      const int idx = x[i];
+      v[i] = v[first]; x[i] = x[first];
+      heap_adjust(v + first, x + first, 0, len, val, idx);
+    }
+}
+
+__device__ inline void nth_element_pairs(float* v, int* x, int n, int nth) {
+  int first = 0, last = n;
+  int depth = 0;
+  for (int t = n; t > 1; t >>= 1) ++depth;             // std::__lg(n)
+  depth *= 2;
+  while (last - first > 3) {
+    if (depth == 0) {
+      nth_heap_select(v, x, first, nth + 1, last);
+      nth_swap(v, x, first, nth);
+      return;
+    }
+    --depth;
+    const int mid = first + (last - first) / 2;
+    nth_median_to_first(v, x, first, first + 1, mid, last - 1);
+    const int cut = nth_partition(v, x, first + 1, last, first);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  nth_insertion_sort(v, x, first, last);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void tal_metrics_kernel(Maps m, const float* __restrict__ pred, const float* __restrict__ gt,
                                                            int n_max, float* __restrict__ align, float* __restrict__ overl,
                                                            int* __restrict__ cand, uint8_t* __restrict__ mask_pos) {
   __shared__ float hv[TOPK];
   __shared__ int hi[TOPK];
+  __shared__ float s_nv[SMALL_A];                      // row copy for the nth_element path (rows shorter than 640 anchors)
+  __shared__ int s_ni[SMALL_A];
   __shared__ int s_wave_cnt[4];
   __shared__ int s_total;
   __shared__ float s_v0;
@@ -144,25 +234,57 @@ __global__ __launch_bounds__(256) void tal_metrics_kernel(Maps m, const float* _
   float* ov = overl + base;
   const float gb[4] = {gx1, gy1, gx2, gy2};
   for (int a = tid; a < m.A; a += 256) {
-    int lvl, cell;
-    float ax, ay;
-    anchor_of(m, a, lvl, cell, ax, ay);
-    const float st = m.stride[lvl];
-    const float px = ax * st, py = ay * st;
+    int lvl = 0, cell = 0;
+    float px, py, st = 1.f;
+    if (m.dec_anchors) {
+      px = m.dec_anchors[2 * a];
+      py = m.dec_anchors[2 * a + 1];
+    } else {
+      float ax, ay;
+      anchor_of(m, a, lvl, cell, ax, ay);
+      st = m.stride[lvl];
+      px = ax * st;
+      py = ay * st;
+    }
     float dmin = fminf(fminf(px - gx1, py - gy1), fminf(gx2 - px, gy2 - py));
     float metric = 0.f, o = 0.f;
     if (dmin > 1e-9f) {
       const float* pb = pred + ((long)b * m.A + a) * 4;
       float pbox[4] = {pb[0] * st, pb[1] * st, pb[2] * st, pb[3] * st};
       o = fmaxf(dy_ciou(gb, pbox), 0.f);
-      float lg = DT<T>::ld(row_ptr<T>(m, b, lvl, cell) + 4 * REG + (label < 0 ? 0 : (label >= m.nc ? m.nc - 1 : label)));
-      float sc = dy_sigmoid(lg);
+      const int lc = label < 0 ? 0 : (label >= m.nc ? m.nc - 1 : label);
+      float sc;
+      if (m.dec_scores) sc = m.dec_scores[((long)b * m.A + a) * m.nc + lc];
+      else sc = dy_sigmoid(DT<T>::ld(row_ptr<T>(m, b, lvl, cell) + 4 * REG + lc));
       metric = powf(sc, 0.5f) * powf(o, 6.0f);
     }
     al[a] = metric;
     ov[a] = o;
   }
   __syncthreads();
+  if (m.A < SMALL_A) {                                  // block-uniform
+    for (int a = tid; a < m.A; a += 256) { s_nv[a] = al[a]; s_ni[a] = a; }
+    __syncthreads();
+    if (tid == 0) nth_element_pairs(s_nv, s_ni, m.A, TOPK - 1);
+    __syncthreads();
+    if (tid < TOPK) {
+      const int a = s_ni[tid];
+      float px, py;
+      if (m.dec_anchors) {
+        px = m.dec_anchors[2 * a];
+        py = m.dec_anchors[2 * a + 1];
+      } else {
+        int lvl, cell;
+        float ax, ay;
+        anchor_of(m, a, lvl, cell, ax, ay);
+        px = ax * m.stride[lvl];
+        py = ay * m.stride[lvl];
+      }
+      const float dmin = fminf(fminf(px - gx1, py - gy1), fminf(gx2 - px, gy2 - py));
+      if (dmin > 1e-9f) mask_pos[base + a] = 1;
+    }
+    return;
+  }
   // initial heap = first TOPK elements (std::__make_heap), v0 = its minimum (heap top)
   if (tid == 0) {
     for (int i = 0; i < TOPK; ++i) { hv[i] = al[i]; hi[i] = i; }
@@ -222,11 +344,17 @@ __global__ __launch_bounds__(256) void tal_metrics_kernel(Maps m, const float* _
     // mask_pos = topk & in_gts & mask_gt (tal.py:129-139)
     if (lane < TOPK) {
       int a = hi[lane];
-      int lvl, cell;
-      float ax, ay;
-      anchor_of(m, a, lvl, cell, ax, ay);
-      const float st = m.stride[lvl];
-      const float px = ax * st, py = ay * st;
+      float px, py;
+      if (m.dec_anchors) {
+        px = m.dec_anchors[2 * a];
+        py = m.dec_anchors[2 * a + 1];
+      } else {
+        int lvl, cell;
+        float ax, ay;
+        anchor_of(m, a, lvl, cell, ax, ay);
+        px = ax * m.stride[lvl];
+        py = ay * m.stride[lvl];
+      }
       float dmin = fminf(fminf(px - gx1, py - gy1), fminf(gx2 - px, gy2 - py));
       if (dmin > 1e-9f) mask_pos[base + a] = 1;
     }
@@ -527,6 +655,7 @@ int make_maps(const dy_det_maps* d, Maps& m, const char* who) {
   DY_CHECK(d && d->n_levels >= 1 && d->n_levels <= 3, "%s: bad maps", who);
   DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16, "%s: bad dtype", who);
   m.B = d->B; m.nc = d->nc; m.nl = d->n_levels;
+  m.dec_scores = nullptr; m.dec_anchors = nullptr;
   int off = 0;
   for (int l = 0; l < 3; ++l) {
     m.off[l] = off;
@@ -568,13 +697,10 @@ extern "C" int dy_loss_decode(const dy_det_maps* d, float* pred_boxes, void* str
   return 0;
 }
 
-extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, const float* gt, const int32_t* counts, int n_max,
-                             float* work_f, int32_t* work_i, uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm,
-                             int32_t* target_label, float* target_box, void* stream) {
-  Maps m;
-  if (int e = make_maps(d, m, "dy_tal_assign")) return e;
-  DY_CHECK(pred_boxes && gt && counts && target_gt_idx && fg_mask && norm && target_label && target_box, "dy_tal_assign: null");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int run_assigner(const Maps& m, int dtype, const float* pred_boxes, const float* gt, const int32_t* counts, int n_max, float* work_f,
+                 int32_t* work_i, uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm, int32_t* target_label,
+                 float* target_box, hipStream_t st) {
   const long BA = (long)m.B * m.A;
   if (n_max == 0) {          // tal.py:106-110
     (void)hipMemsetAsync(target_gt_idx, 0, BA * 4, st);
@@ -592,7 +718,7 @@ extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, cons
   (void)hipMemsetAsync(work_b, 0, R, st);
   (void)hipMemsetAsync(work_f, 0, (2 * R + 2L * m.B * n_max) * sizeof(float), st);
   dim3 grid(n_max, m.B);
-  if (d->dtype == DY_F32) tal_metrics_kernel<float><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
+  if (dtype == DY_F32) tal_metrics_kernel<float><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
   else tal_metrics_kernel<bf16_t><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
   DY_LAUNCH_CHECK();
   int blocks = dy_cdiv(BA, 256);
@@ -604,6 +730,33 @@ extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, cons
                                              target_label, target_box);
   DY_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int dy_tal_assign(const dy_det_maps* d, const float* pred_boxes, const float* gt, const int32_t* counts, int n_max,
+                             float* work_f, int32_t* work_i, uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm,
+                             int32_t* target_label, float* target_box, void* stream) {
+  Maps m;
+  if (int e = make_maps(d, m, "dy_tal_assign")) return e;
+  DY_CHECK(pred_boxes && gt && counts && target_gt_idx && fg_mask && norm && target_label && target_box, "dy_tal_assign: null");
+  return run_assigner(m, d->dtype, pred_boxes, gt, counts, n_max, work_f, work_i, work_b, target_gt_idx, fg_mask, norm, target_label,
+                      target_box, (hipStream_t)stream);
+}
+
+extern "C" int dy_tal_assign_decoded(const float* pd_scores, const float* pd_bboxes, const float* anc_points, const float* gt,
+                                     const int32_t* counts, int B, int A, int nc, int n_max, float* work_f, int32_t* work_i,
+                                     uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm, int32_t* target_label,
+                                     float* target_box, void* stream) {
+  DY_CHECK(pd_scores && pd_bboxes && anc_points && gt && counts && target_gt_idx && fg_mask && norm && target_label && target_box,
+           "dy_tal_assign_decoded: null");
+  DY_CHECK(B > 0 && nc > 0 && A >= TOPK && n_max >= 0, "dy_tal_assign_decoded: empty problem (A=%d)", A);
+  Maps m;
+  for (int l = 0; l < 3; ++l) { m.map[l] = nullptr; m.ld[l] = 0; m.h[l] = 1; m.w[l] = 1; m.stride[l] = 1.f; m.off[l] = l ? A : 0; }
+  m.off[3] = A;
+  m.B = B; m.nc = nc; m.nl = 1; m.A = A;
+  m.dec_scores = pd_scores; m.dec_anchors = anc_points;
+  return run_assigner(m, DY_F32, pd_bboxes, gt, counts, n_max, work_f, work_i, work_b, target_gt_idx, fg_mask, norm, target_label,
+                      target_box, (hipStream_t)stream);
 }
 
 extern "C" int dy_loss_fwd(const dy_det_maps* d, const float* pred_boxes, const uint8_t* fg_mask, const float* norm,

@@ -133,20 +133,48 @@ def padded_channels(t):
 
 # ------------------------------------------------------------------------------------------------ scratch arena
 class _Arena:
-    """Zero-initialised double scratch for per-channel statistics; one fill per step instead of one per conv."""
+    """Zero-initialised double scratch for per-channel statistics; one fill per step instead of one per conv.
+
+    Streams: reset() runs on the compute stream at the start of a forward pass and remembers it.  A chunk that has to be added in
+    the middle of a pass (the first pass, before the right size is known) may be requested from a branch stream (Detect levels,
+    weight gradients): it is then allocated AND zeroed on the compute stream, every side stream is made to wait for that fill
+    (dy_stream_fork), and the chunk it replaces stays alive until the next reset(), so that no kernel of another stream can see
+    memory that is being filled or has gone back to the allocator."""
 
     def __init__(self):
         self.buf = None
         self.off = 0
         self.used = 0          # doubles handed out since the last reset
         self.chunks = 0        # buffers created since the last reset
+        self.retired = []      # chunks replaced since the last reset (kept alive: other streams may still use their slices)
+        self.main_raw = None   # hipStream_t of the compute stream (set by reset)
+
+    def _new_chunk(self, cap, device):
+        cur = stream()
+        main_raw = self.main_raw if self.main_raw is not None else cur
+        if cur == main_raw:
+            buf = torch.zeros(cap, dtype=torch.float64, device=device)
+        else:
+            with torch.cuda.stream(torch.cuda.ExternalStream(main_raw, device=device)):
+                buf = torch.zeros(cap, dtype=torch.float64, device=device)
+        # every side stream that may take a slice of this chunk waits for the fill
+        others = [s.cuda_stream for s in _branch["streams"]]
+        if _wg_side.raw is not None:
+            others.append(_wg_side.raw)
+        if cur != main_raw and cur not in others:
+            others.append(cur)
+        for raw in others:
+            call("dy_stream_fork", main_raw, raw)
+        return buf
 
     def alloc(self, n, device):
         n = round_up(n, 2)
         self.used += n
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
             cap = max(1 << 18, 4 * n)                # overflow chunk; reset() replaces the chunks by one buffer of the right size
-            self.buf = torch.zeros(cap, dtype=torch.float64, device=device)
+            if self.buf is not None:
+                self.retired.append(self.buf)
+            self.buf = self._new_chunk(cap, device)
             self.off = 0
             self.chunks += 1
         out = self.buf[self.off:self.off + n]
@@ -154,6 +182,8 @@ class _Arena:
         return out
 
     def reset(self):
+        self.main_raw = stream() if torch.cuda.is_available() else None
+        self.retired.clear()
         if self.chunks > 1 and self.buf is not None:
             self.buf = torch.zeros(int(self.used * 1.25) + 1024, dtype=torch.float64, device=self.buf.device)
         elif self.buf is not None and self.off:

@@ -170,13 +170,54 @@ class RcoveryDetectionLoss(v8DetectionLoss):
 class TaskAlignedAssigner:
     """reference tal.py:59-243 (topk must be 10, alpha 0.5, beta 6.0: the constants compiled into the kernel).
 
-    The reference signature takes decoded scores/boxes; the HIP assigner works from the raw Detect maps, so this class
-    exposes `assign_from_maps`; the criterion uses it internally."""
+    `forward(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt)` is the reference's own call (tal.py:84-132) on the
+    HIP assigner (dy_tal_assign_decoded); the criterion itself goes from the raw Detect maps (`assign_from_maps`, no decoded
+    [B,A,nc] score tensor is ever materialised there)."""
 
     def __init__(self, topk=13, num_classes=80, alpha=1.0, beta=6.0, eps=1e-9):
         if (topk, alpha, beta) != (10, 0.5, 6.0):
             raise NotImplementedError("HIP TaskAlignedAssigner is built for topk=10, alpha=0.5, beta=6.0 (loss.py:120)")
         self.topk, self.num_classes, self.alpha, self.beta, self.eps = topk, num_classes, alpha, beta, eps
+        self.bg_idx = num_classes
 
     def assign_from_maps(self, maps, strides, batch_idx, cls, bboxes, n_max=None):
         return assign([ops.as_nhwc(m) for m in maps], [float(s) for s in strides], self.num_classes, batch_idx, cls, bboxes, n_max)
+
+    @torch.no_grad()
+    def forward(self, pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt):
+        """Returns (target_labels [B,A] int64, target_bboxes [B,A,4], target_scores [B,A,nc], fg_mask [B,A] bool,
+        target_gt_idx [B,A] int64) like tal.py:84-132."""
+        ops.require_gpu(pd_scores)
+        dev = pd_scores.device
+        f32 = torch.float32
+        B, A, nc = pd_scores.shape
+        n = gt_bboxes.shape[1]
+        if n == 0:                                            # tal.py:106-110
+            return (torch.full((B, A), float(self.bg_idx), dtype=pd_scores.dtype, device=dev), torch.zeros_like(pd_bboxes),
+                    torch.zeros_like(pd_scores), torch.zeros((B, A), dtype=pd_scores.dtype, device=dev),
+                    torch.zeros((B, A), dtype=pd_scores.dtype, device=dev))
+        sc = pd_scores.detach().to(dev, f32).contiguous()
+        bx = pd_bboxes.detach().to(dev, f32).contiguous()
+        an = anc_points.detach().to(dev, f32).contiguous()
+        mk = mask_gt.to(dev, f32).reshape(B, n, 1)
+        gt = torch.cat((gt_labels.to(dev, f32).reshape(B, n, 1), gt_bboxes.to(dev, f32) * mk), 2).contiguous()    # masked rows: zero box
+        counts = torch.full((B,), n, dtype=torch.int32, device=dev)
+        st = stream()
+        tgi = torch.empty((B, A), dtype=torch.int32, device=dev)
+        fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+        norm = torch.empty((B, A), dtype=f32, device=dev)
+        tl = torch.empty((B, A), dtype=torch.int32, device=dev)
+        tb = torch.empty((B, A, 4), dtype=f32, device=dev)
+        R = B * n * A
+        work_f = torch.empty(2 * R + 2 * B * n, dtype=f32, device=dev)
+        work_i = torch.empty(R, dtype=torch.int32, device=dev)
+        work_b = torch.empty(R, dtype=torch.uint8, device=dev)
+        call("dy_tal_assign_decoded", ptr(sc), ptr(bx), ptr(an), ptr(gt), ptr(counts), B, A, nc, n, ptr(work_f), ptr(work_i), ptr(work_b),
+             ptr(tgi), ptr(fg), ptr(norm), ptr(tl), ptr(tb), st)
+        fgb = fg.bool()
+        labels = tl.long().clamp_(min=0)
+        scores = torch.zeros((B, A, nc), dtype=f32, device=dev)
+        scores.scatter_(2, labels.clamp(max=nc - 1).unsqueeze(-1), (norm * fgb).unsqueeze(-1))
+        return labels, tb, scores, fgb, tgi.long()
+
+    __call__ = forward

@@ -204,6 +204,13 @@ int dy_loss_decode(const dy_det_maps* m, float* pred_boxes, void* stream);
 int dy_tal_assign(const dy_det_maps* m, const float* pred_boxes, const float* gt, const int32_t* counts, int n_max,
                   float* work_f, int32_t* work_i, uint8_t* work_b, int32_t* target_gt_idx, uint8_t* fg_mask, float* norm,
                   int32_t* target_label, float* target_box, void* stream);
+/* The same assigner on TaskAlignedAssigner.forward's own arguments (U/utils/tal.py:84-132): class probabilities pd_scores
+ * [B,A,nc] f32, decoded boxes pd_bboxes [B,A,4] f32 in pixels, anchor points [A,2] in pixels; gt rows = (label, x1,y1,x2,y2) with
+ * masked-out rows zeroed, counts[b] = rows of image b to consider.  Outputs as dy_tal_assign. */
+int dy_tal_assign_decoded(const float* pd_scores, const float* pd_bboxes, const float* anc_points, const float* gt,
+                          const int32_t* counts, int B, int A, int nc, int n_max, float* work_f, int32_t* work_i, uint8_t* work_b,
+                          int32_t* target_gt_idx, uint8_t* fg_mask, float* norm, int32_t* target_label, float* target_box,
+                          void* stream);
 /* loss sums: acc[0]=sum target_scores, acc[1]=BCE sum, acc[2]=sum (1-ciou)*w, acc[3]=sum dfl*w (acc zeroed first) */
 int dy_loss_fwd(const dy_det_maps* m, const float* pred_boxes, const uint8_t* fg_mask, const float* norm,
                 const int32_t* target_label, const float* target_box, double* acc, void* stream);

@@ -362,3 +362,53 @@ def test_model_gradients_with_branch_streams_and_autograd_gradients():
     assert abs(r["loss"] - r["oracle_loss"]) <= 1e-4 * abs(r["oracle_loss"])
     assert r["grad_finite"] and r["n_nograd"] == 0
     assert r["median_grad_rel"] < 1e-2 and r["worst_grad_rel"] < 0.1, r["worst5"]
+
+
+@pytest.mark.parametrize("name", ["g4_assigner", "g4_assigner_b"])
+def test_assigner_forward_on_reference_vectors(name):
+    """TaskAlignedAssigner.forward(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt) -- the reference's own call
+    (tal.py:84-132) -- through dy_tal_assign_decoded on the inputs captured from the reference (incl. the crafted zero-metric ties).
+    84 / 336 anchors per row: torch.topk takes std::nth_element there, which the kernel reproduces (integer outputs bit-exact)."""
+    from dedark_yolo_amd.utils.loss import TaskAlignedAssigner
+    g = gold(name)
+    nc = int(g["nc"])
+    asg = TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)
+    tl, tb, ts, fg, gi = asg(g["scores"].cuda(), g["boxes"].cuda(), g["anc"].cuda(), g["lab"].cuda(), g["gt"].cuda(), g["mask"].cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(fg.cpu(), g["fg_mask"].bool()), "fg_mask"
+    assert torch.equal(gi.cpu(), g["target_gt_idx"].long()), "target_gt_idx"
+    assert torch.equal(tl.cpu(), g["target_labels"].long()), "target_labels"
+    assert torch.equal(tb.cpu(), g["target_bboxes"]), "target_bboxes"
+    close(ts.cpu(), g["target_scores"], 1e-5, 1e-6, "target_scores")
+
+
+def test_assigner_small_rows_vs_oracle_with_many_ties():
+    """Rows of 100 .. 600 anchors (below torch's partial_sort switch at 64 * k) with few positive candidates per ground truth, so that
+    the top-10 are filled up with zero-metric anchors: the integer outputs must still equal the oracle's (= torch.topk's) choice."""
+    from oracle import loss as oloss
+    from dedark_yolo_amd.utils.loss import TaskAlignedAssigner
+    g = np.random.default_rng(123)
+    for A_side, n in ((10, 3), (15, 5), (20, 6), (24, 8)):
+        A, B, nc = A_side * A_side, 3, 7
+        st = 8.0
+        ys, xs = np.meshgrid(np.arange(A_side) + 0.5, np.arange(A_side) + 0.5, indexing="ij")
+        anc = torch.tensor(np.stack((xs.ravel(), ys.ravel()), 1) * st, dtype=torch.float32)
+        c = g.uniform(2 * st, (A_side - 2) * st, (B, n, 2))
+        wh = g.uniform(1.2 * st, 3.5 * st, (B, n, 2))                      # small boxes: 1 .. 12 cells inside each
+        gtb = torch.tensor(np.concatenate((c - wh / 2, c + wh / 2), 2), dtype=torch.float32)
+        lab = torch.tensor(g.integers(0, nc, (B, n, 1)), dtype=torch.float32)
+        mask = torch.ones(B, n, 1)
+        mask[1, n - 1] = 0
+        gtb[1, n - 1] = 0
+        pc = anc[None].repeat(B, 1, 1) + torch.tensor(g.normal(0, 3, (B, A, 2)), dtype=torch.float32)
+        pwh = torch.tensor(g.uniform(1.0 * st, 4.0 * st, (B, A, 2)), dtype=torch.float32)
+        boxes = torch.cat((pc - pwh / 2, pc + pwh / 2), 2)
+        scores = torch.tensor(g.random((B, A, nc)), dtype=torch.float32)
+        want = oloss.tal_assign(scores, boxes, anc, lab, gtb, mask, nc)
+        asg = TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)
+        tl, tb, ts, fg, gi = asg(scores.cuda(), boxes.cuda(), anc.cuda(), lab.cuda(), gtb.cuda(), mask.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(fg.cpu(), want[3]), (A, "fg_mask")
+        assert torch.equal(gi.cpu(), want[4]), (A, "target_gt_idx")
+        assert torch.equal(tl.cpu(), want[0].long()), (A, "target_labels")
+        close(ts.cpu(), want[2], 1e-5, 1e-6, f"A={A} target_scores")

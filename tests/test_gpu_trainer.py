@@ -282,3 +282,37 @@ def test_preprocess_batch_vs_reference_fixture():
         assert float((out["img"].cpu() - torch.from_numpy(z[f"{tag}_img"])).abs().max()) <= 1e-6, tag
         assert float((out["clean_img"].cpu() - torch.from_numpy(z[f"{tag}_clean"])).abs().max()) <= 1e-6, tag
         assert abs(float(out["recovery_loss_batch"]) - float(z[f"{tag}_rec"])) <= 1e-6, tag
+
+
+def test_arena_growth_inside_branch_streams():
+    """The statistics arena has to grow in the middle of a pass when it is too small (always in the first step).  Force that to
+    happen inside Detect's branch streams and in the side-stream weight gradients (a 64-double arena: every request overflows) and
+    compare with the single-stream run: a chunk that were zero-filled on a branch stream, or handed out before its fill was ordered
+    for the other streams, would corrupt the BatchNorm batch statistics."""
+    import bench
+    from dedark_yolo_amd import ops
+
+    def run(on):
+        tr = _tiny_trainer("SGD", batch=64)
+        ops.enable_wgrad_stream(on)
+        ops.enable_branch_streams(on)
+        out = []
+        for i in range(2):
+            ops.arena.buf = torch.zeros(64, dtype=torch.float64, device="cuda")      # too small for any layer
+            ops.arena.off, ops.arena.used, ops.arena.chunks = 0, 0, 1
+            b = bench.synth_batch(60 + i, 4, 96, 20, "cuda")
+            tr.args.dark_param = b.pop("gamma")
+            loss, _ = tr.train_step(b, [0.01] * 3, 0.9)
+            out.append(float(loss))
+        torch.cuda.synchronize()
+        return out, tr.flat.buf_flat.detach().clone(), tr.flat.g.detach().clone()
+
+    try:
+        l1, b1, g1 = run(True)
+        l0, b0, g0 = run(False)
+    finally:
+        ops.enable_wgrad_stream(True)
+        ops.enable_branch_streams(True)
+    assert np.allclose(l1, l0, rtol=2e-5, atol=1e-5), (l1, l0)
+    assert float((b1 - b0).abs().max()) <= 1e-5 * max(1.0, float(b0.abs().max()))          # BatchNorm running statistics
+    assert float((g1 - g0).abs().max()) <= 2e-4 * max(1e-3, float(g0.abs().max()))
