@@ -192,16 +192,18 @@ __global__ void asff_fwd_kernel(const T* __restrict__ x0, long ld0, const T* __r
   const int lane = threadIdx.x & 63;
   const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   for (long px = wave; px < pixels; px += nwaves) {
-    float l0 = DT<T>::ld(lg + px * ldl), l1 = DT<T>::ld(lg + px * ldl + 1), l2 = DT<T>::ld(lg + px * ldl + 2);
+    // x2 == nullptr: two-level fusion (AsffDoubLevel), the softmax runs over two logits
+    float l0 = DT<T>::ld(lg + px * ldl), l1 = DT<T>::ld(lg + px * ldl + 1), l2 = x2 ? DT<T>::ld(lg + px * ldl + 2) : -INFINITY;
     float mx = fmaxf(l0, fmaxf(l1, l2));
-    float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+    float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = x2 ? expf(l2 - mx) : 0.f;
     float inv = 1.f / (e0 + e1 + e2);
     float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
     for (int g = lane; g < CG; g += 64) {
       float a[VE], b[VE], c[VE];
       ldvec<T>(x0 + px * ld0 + g * VE, a);
       ldvec<T>(x1 + px * ld1 + g * VE, b);
-      ldvec<T>(x2 + px * ld2 + g * VE, c);
+      if (x2) ldvec<T>(x2 + px * ld2 + g * VE, c);
+      else { for (int e = 0; e < VE; ++e) c[e] = 0.f; }
 #pragma unroll
       for (int e = 0; e < VE; ++e) a[e] = a[e] * w0 + b[e] * w1 + c[e] * w2;
       stvec<T>(out + px * ldo + g * VE, a);
@@ -220,9 +222,9 @@ __global__ void asff_bwd_kernel(const T* __restrict__ dout, long lddo, const T* 
   const int lane = threadIdx.x & 63;
   const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   for (long px = wave; px < pixels; px += nwaves) {
-    float l0 = DT<T>::ld(lg + px * ldl), l1 = DT<T>::ld(lg + px * ldl + 1), l2 = DT<T>::ld(lg + px * ldl + 2);
+    float l0 = DT<T>::ld(lg + px * ldl), l1 = DT<T>::ld(lg + px * ldl + 1), l2 = x2 ? DT<T>::ld(lg + px * ldl + 2) : -INFINITY;
     float mx = fmaxf(l0, fmaxf(l1, l2));
-    float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+    float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = x2 ? expf(l2 - mx) : 0.f;
     float inv = 1.f / (e0 + e1 + e2);
     float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -231,7 +233,8 @@ __global__ void asff_bwd_kernel(const T* __restrict__ dout, long lddo, const T* 
       ldvec<T>(dout + px * lddo + g * VE, go);
       ldvec<T>(x0 + px * ld0 + g * VE, a);
       ldvec<T>(x1 + px * ld1 + g * VE, b);
-      ldvec<T>(x2 + px * ld2 + g * VE, c);
+      if (x2) ldvec<T>(x2 + px * ld2 + g * VE, c);
+      else { for (int e = 0; e < VE; ++e) c[e] = 0.f; }
 #pragma unroll
       for (int e = 0; e < VE; ++e) { d0 += go[e] * a[e]; d1 += go[e] * b[e]; d2 += go[e] * c[e]; }
       T* p0 = dx0 + px * ldd0 + g * VE;
@@ -245,17 +248,19 @@ __global__ void asff_bwd_kernel(const T* __restrict__ dout, long lddo, const T* 
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] += go[e] * w1;
       stvec<T>(p1, o);
-      if (acc2) ldvec<T>(p2, o); else { for (int e = 0; e < VE; ++e) o[e] = 0.f; }
+      if (x2) {
+        if (acc2) ldvec<T>(p2, o); else { for (int e = 0; e < VE; ++e) o[e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < VE; ++e) o[e] += go[e] * w2;
-      stvec<T>(p2, o);
+        for (int e = 0; e < VE; ++e) o[e] += go[e] * w2;
+        stvec<T>(p2, o);
+      }
     }
     d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
     if (lane == 0) {
       float dot = w0 * d0 + w1 * d1 + w2 * d2;
       DT<T>::st(dlg + px * lddl, w0 * (d0 - dot));
       DT<T>::st(dlg + px * lddl + 1, w1 * (d1 - dot));
-      DT<T>::st(dlg + px * lddl + 2, w2 * (d2 - dot));
+      if (2 < lg_width) DT<T>::st(dlg + px * lddl + 2, w2 * (d2 - dot));        // (0 in the two-level mode: w2 == 0)
       for (int j = 3; j < lg_width; ++j) DT<T>::st(dlg + px * lddl + j, 0.f);
     }
   }
@@ -377,9 +382,10 @@ extern "C" int dy_asff_fuse_fwd(const void* x0, int64_t ld0, const void* x1, int
                                 void* stream) {
   if (int e = check_view("dy_asff_fuse_fwd(x0)", x0, ld0, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_fwd(x1)", x1, ld1, C, dtype)) return e;
-  if (int e = check_view("dy_asff_fuse_fwd(x2)", x2, ld2, C, dtype)) return e;
+  if (x2)
+    if (int e = check_view("dy_asff_fuse_fwd(x2)", x2, ld2, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_fwd(out)", out, ldo, C, dtype)) return e;
-  DY_CHECK(logits && ldl >= 3, "dy_asff_fuse_fwd: bad logits");
+  DY_CHECK(logits && ldl >= (x2 ? 3 : 2), "dy_asff_fuse_fwd: bad logits");
   long waves = pixels;
   int blocks = (int)((waves + 3) / 4);
   if (blocks > 4096) blocks = 4096;
@@ -402,11 +408,13 @@ extern "C" int dy_asff_fuse_bwd(const void* dout, int64_t lddo, const void* x0, 
   if (int e = check_view("dy_asff_fuse_bwd(dout)", dout, lddo, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_bwd(x0)", x0, ld0, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_bwd(x1)", x1, ld1, C, dtype)) return e;
-  if (int e = check_view("dy_asff_fuse_bwd(x2)", x2, ld2, C, dtype)) return e;
+  if (x2)
+    if (int e = check_view("dy_asff_fuse_bwd(x2)", x2, ld2, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_bwd(dx0)", dx0, ldd0, C, dtype)) return e;
   if (int e = check_view("dy_asff_fuse_bwd(dx1)", dx1, ldd1, C, dtype)) return e;
-  if (int e = check_view("dy_asff_fuse_bwd(dx2)", dx2, ldd2, C, dtype)) return e;
-  DY_CHECK(logits && dlogits && ldl >= 3 && lddl >= 3, "dy_asff_fuse_bwd: bad logits");
+  if (x2)
+    if (int e = check_view("dy_asff_fuse_bwd(dx2)", dx2, ldd2, C, dtype)) return e;
+  DY_CHECK(logits && dlogits && ldl >= (x2 ? 3 : 2) && lddl >= (x2 ? 3 : 2), "dy_asff_fuse_bwd: bad logits");
   int blocks = (int)((pixels + 3) / 4);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;

@@ -17,7 +17,7 @@ from .. import ops
 from .._C import ACT_LEAKY, ACT_NONE, ACT_SILU, call
 from ..ops import as_nhwc, conv_backward, conv_forward, copy2d, empty_nhwc, ld_of, ptr, stream
 
-__all__ = ("Conv", "Concat", "Bottleneck", "C2f", "SPPF", "Upsample", "AsffTribeLevel", "RFBblock", "DFL", "Detect",
+__all__ = ("Conv", "Concat", "Bottleneck", "C2f", "SPPF", "Upsample", "AsffTribeLevel", "AsffDoubLevel", "RFBblock", "DFL", "Detect", "AsffDetect",
            "lowlight_recovery", "ExtractParameters2", "autopad")
 
 
@@ -381,6 +381,70 @@ class AsffTribeLevel(DyModule):
         return dx0, dx1, dx2
 
 
+class AsffDoubLevel(DyModule):
+    """2-level adaptive spatial feature fusion (reference block.py:118-162).  Inputs (P4-like 512 ch, P3-like 256 ch at twice the
+    resolution); level 0 fuses at the coarse size (512 ch out), level 1 at the fine size (256 ch out)."""
+
+    def __init__(self, level):
+        super().__init__()
+        self.level = level
+        self.dim = [512, 256]
+        self.inter_dim = self.dim[level]
+        if level == 0:
+            self.stride_level_1 = AddConv(256, self.inter_dim, 3, 2)
+            self.expand = AddConv(self.inter_dim, 512, 3, 1)
+        elif level == 1:
+            self.compress_level_0 = AddConv(512, self.inter_dim, 1, 1)
+            self.expand = AddConv(self.inter_dim, 256, 3, 1)
+        compress_c = 16
+        self.weight_level_0 = AddConv(self.inter_dim, compress_c, 1, 1)
+        self.weight_level_1 = AddConv(self.inter_dim, compress_c, 1, 1)
+        self.weight_levels = nn.Conv2d(compress_c * 2, 2, kernel_size=1, stride=1, padding=0)
+
+    def _fwd(self, tape, x0, x1):
+        tr = self.training
+        if self.level == 0:
+            r0 = x0
+            r1 = self.stride_level_1._fwd(tape, x1, tr)
+        else:
+            r0 = ops.upsample_fwd(self.compress_level_0._fwd(tape, x0, tr), 2)
+            r1 = x1
+        B, Cc, H, W = r0.shape
+        wv = empty_nhwc(B, 32, H, W, r0.dtype, r0.device)
+        self.weight_level_0._fwd(tape, r0, tr, out=wv[:, 0:16])
+        self.weight_level_1._fwd(tape, r1, tr, out=wv[:, 16:32])
+        logits = plain_conv_fwd(tape, self.weight_levels, wv)                 # [B,2,H,W] view of a channel-padded buffer
+        fused = empty_nhwc(B, Cc, H, W, r0.dtype, r0.device)
+        call("dy_asff_fuse_fwd", ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), None, 0, ptr(logits), ld_of(logits),
+             ptr(fused), ld_of(fused), B * H * W, Cc, ops.dt_id(r0.dtype), stream())
+        if tape is not None:
+            tape.push(dict(r0=r0, r1=r1, logits=logits))
+        return self.expand._fwd(tape, fused, tr)
+
+    def _bwd(self, tape, dy, needs=(True, True)):
+        dfused = conv_backward(tape, dy)
+        s = tape.pop()
+        r0, r1, logits = s["r0"], s["r1"], s["logits"]
+        B, Cc, H, W = r0.shape
+        dt, dev = r0.dtype, r0.device
+        dr = [empty_nhwc(B, Cc, H, W, dt, dev) for _ in range(2)]
+        lw = ld_of(logits)
+        dlog = empty_nhwc(B, lw, H, W, dt, dev)
+        call("dy_asff_fuse_bwd", ptr(dfused), ld_of(dfused), ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), None, 0,
+             ptr(logits), lw, ptr(dr[0]), ld_of(dr[0]), ptr(dr[1]), ld_of(dr[1]), None, 0, ptr(dlog), lw,
+             B * H * W, Cc, 0, 0, 0, ops.dt_id(dt), stream())
+        dwv = conv_backward(tape, dlog[:, :2])                                # weight_levels -> [B,32,H,W]
+        conv_backward(tape, dwv[:, 16:32], dx_out=dr[1], accumulate=True)     # weight_level_1
+        conv_backward(tape, dwv[:, 0:16], dx_out=dr[0], accumulate=True)
+        if self.level == 0:
+            dx1 = conv_backward(tape, dr[1])                                  # stride_level_1
+            dx0 = dr[0]
+        else:
+            dx1 = dr[1]
+            dx0 = conv_backward(tape, ops.upsample_bwd(dr[0], 2))             # compress_level_0
+        return dx0, dx1
+
+
 class RFBblock(DyModule):
     """Receptive-field block: four branches of biased convs with dilations 1/1/2/3, concatenated
     (reference block.py:703-734).  Branch outputs are written into slices of the output buffer."""
@@ -543,6 +607,39 @@ class Detect(DyModule):
         for a, b, s in zip(self.cv2, self.cv3, self.stride):
             a[-1].bias.data[:] = 1.0
             b[-1].bias.data[:self.nc] = math.log(5 / self.nc / (640 / s) ** 2)
+
+
+class AsffDetect(Detect):
+    """Detect head with one 1x1 conv per branch and level (reference head.py:105-174): cv2[i] = Conv2d(ch_i, 64, 1),
+    cv3[i] = Conv2d(ch_i, nc, 1); decode, anchors and bias_init as Detect."""
+
+    def __init__(self, nc=80, ch=()):
+        DyModule.__init__(self)
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        self.cv2 = nn.ModuleList(nn.Sequential(nn.Conv2d(x, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(nn.Conv2d(x, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max)
+
+    def _level_fwd(self, tape, i, x):
+        B, _, H, W = x.shape
+        nc_pad = ops.round_up(self.nc, ops.vec_elems(x.dtype))
+        r = 4 * self.reg_max
+        buf = empty_nhwc(B, r + nc_pad, H, W, x.dtype, x.device)
+        plain_conv_fwd(tape, self.cv2[i][0], x, out=buf[:, :r])
+        plain_conv_fwd(tape, self.cv3[i][0], x, out=buf[:, r:r + nc_pad])
+        return buf[:, :self.no]
+
+    def _level_bwd(self, tape, i, g):
+        r = 4 * self.reg_max
+        nc_pad = ops.round_up(self.nc, ops.vec_elems(g.dtype))
+        if ld_of(g) < r + nc_pad:
+            raise RuntimeError("AsffDetect: gradient map lacks channel padding")
+        dx = conv_backward(tape, g[:, r:r + self.nc])                      # cv3[i][0]
+        return conv_backward(tape, g[:, :r], dx_out=dx, accumulate=True)   # cv2[i][0]
 
 
 # ------------------------------------------------------------------------------------------------ low-light front-end

@@ -14,12 +14,12 @@ import torch.nn as nn
 import yaml
 
 from .. import ops
-from .modules import (AsffTribeLevel, C2f, Concat, Conv, Detect, RFBblock, SPPF, Upsample, lowlight_recovery)
+from .modules import (AsffDetect, AsffDoubLevel, AsffTribeLevel, C2f, Concat, Conv, Detect, RFBblock, SPPF, Upsample, lowlight_recovery)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg" / "models" / "v8"
 
-_REGISTRY = dict(Conv=Conv, C2f=C2f, SPPF=SPPF, Concat=Concat, Detect=Detect, AsffTribeLevel=AsffTribeLevel,
-                 RFBblock=RFBblock, lowlight_recovery=lowlight_recovery)
+_REGISTRY = dict(Conv=Conv, C2f=C2f, SPPF=SPPF, Concat=Concat, Detect=Detect, AsffDetect=AsffDetect, AsffTribeLevel=AsffTribeLevel,
+                 AsffDoubLevel=AsffDoubLevel, RFBblock=RFBblock, lowlight_recovery=lowlight_recovery)
 _REGISTRY["nn.Upsample"] = Upsample
 
 
@@ -51,59 +51,107 @@ def yaml_model_load(path):
     return d
 
 
+# ------------------------------------------------------------------------------------------------ yaml -> graph
+# The yaml grammar ([from, repeats, module, args] rows, `scales`, 'nc' substitution) and the channel rules per module kind are
+# the drop-in contract (reference parse_model, tasks.py:803-921).  Here each module kind registers ONE rule that turns a row into
+# (constructor arguments, output channels, module repeats), and the rows are compiled ONCE into a flat execution plan
+# (GraphPlan: per node its source nodes and the node after which its output is dead), which forward passes just walk.
+class _Row:
+    __slots__ = ("index", "src", "repeats", "kind", "args", "ch_in", "nc", "width", "max_ch")
+
+
+def _scaled_width(c, row):
+    return make_divisible(min(c, row.max_ch) * row.width, 8)
+
+
+def _rule_conv_like(row):                 # Conv, SPPF: [c_out, ...] -> (c_in, scaled c_out, ...)
+    c2 = row.args[0] if row.args[0] == row.nc else _scaled_width(row.args[0], row)
+    return [row.ch_in[0], c2, *row.args[1:]], c2, row.repeats
+
+
+def _rule_c2f(row):                       # the row's repeat count becomes the number of inner Bottlenecks
+    args, c2, _ = _rule_conv_like(row)
+    return [args[0], args[1], row.repeats, *args[2:]], c2, 1
+
+
+_RULES = {
+    Conv: _rule_conv_like, SPPF: _rule_conv_like, C2f: _rule_c2f,
+    Concat: lambda r: (r.args, sum(r.ch_in), r.repeats),
+    lowlight_recovery: lambda r: (r.args, r.args[0], r.repeats),
+    AsffTribeLevel: lambda r: (r.args, 512 if r.args[0] in (0, 1) else 256, r.repeats),       # tasks.py:892-896
+    AsffDoubLevel: lambda r: (r.args, 512 if r.args[0] == 0 else 256, r.repeats),
+    Detect: lambda r: ([*r.args, list(r.ch_in)], r.ch_in[0], r.repeats),
+    AsffDetect: lambda r: ([*r.args, list(r.ch_in)], r.ch_in[0], r.repeats),
+}
+_PASS_THROUGH = lambda r: (r.args, r.ch_in[0], r.repeats)         # Upsample, RFBblock: channels unchanged
+
+
+class GraphPlan:
+    """Flat execution plan of a layer graph: nodes[i] = (module, sources, takes_list); a source is an absolute node index or -1
+    for the network input.  `dead_after[i]` lists the nodes whose outputs have their last consumer at node i."""
+
+    def __init__(self, layers):
+        self.nodes, n = [], len(layers)
+        last_use = [-1] * n
+        for i, m in enumerate(layers):
+            f = m.f
+            rel = [f] if isinstance(f, int) else list(f)
+            src = tuple((i - 1 if j == -1 else (j if j >= 0 else i + j)) for j in rel)
+            self.nodes.append((m, src, not isinstance(f, int)))
+            for sidx in src:
+                if sidx >= 0:
+                    last_use[sidx] = i
+        self.dead_after = [[] for _ in range(n)]
+        for sidx, i in enumerate(last_use):
+            if 0 <= i < n - 1:
+                self.dead_after[i].append(sidx)
+        self.save = sorted({sidx for m, src, _ in self.nodes for sidx, j in zip(src, ([m.f] if isinstance(m.f, int) else m.f)) if j != -1})
+
+    def run(self, x, call_layer):
+        outs = [None] * len(self.nodes)
+        for i, (m, src, as_list) in enumerate(self.nodes):
+            ins = [x if sidx < 0 else outs[sidx] for sidx in src]
+            outs[i] = call_layer(m, ins if as_list else ins[0])
+            for sidx in self.dead_after[i]:
+                outs[sidx] = None                 # last consumer done: the buffer goes back to the allocator now
+        return outs[-1]
+
+
 def parse_model(d, ch, verbose=False):
-    """yaml dict -> (nn.Sequential, save list); channel rules of the reference parse_model (tasks.py:803-921)."""
+    """yaml dict -> (nn.Sequential of layers carrying .i / .f / .type / .np, save list) -- the reference's return contract."""
     import ast
-    max_channels = float("inf")
     nc, scales = d.get("nc"), d.get("scales")
-    depth, width = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0)
+    depth, width, max_ch = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0), float("inf")
     if scales:
-        scale = d.get("scale") or tuple(scales.keys())[0]
-        depth, width, max_channels = scales[scale]
-    ch = [ch]
-    layers, save, c2 = [], [], ch[-1]
-    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
-        if mname not in _REGISTRY:
-            raise NotImplementedError(f"module '{mname}' is outside the Dedark-YOLO hot path (SURVEY.md 8)")
-        m = _REGISTRY[mname]
-        args = list(args)
-        for j, a in enumerate(args):
-            if isinstance(a, str):
-                if a == "nc":
-                    args[j] = nc
-                else:
-                    with contextlib.suppress(ValueError, SyntaxError):
-                        args[j] = ast.literal_eval(a)
-        n = n_ = max(round(n * depth), 1) if n > 1 else n
-        if m in (Conv, C2f, SPPF):
-            c1, c2 = ch[f], args[0]
-            if c2 != nc:
-                c2 = make_divisible(min(c2, max_channels) * width, 8)
-            args = [c1, c2, *args[1:]]
-            if m is C2f:
-                args.insert(2, n)
-                n = 1
-        elif m is Concat:
-            c2 = sum(ch[x] for x in f)
-        elif m is lowlight_recovery:
-            c2 = args[0]
-        elif m is AsffTribeLevel:
-            c2 = 512 if args[0] in (0, 1) else 256
-        elif m is Detect:
-            args.append([ch[x] for x in f])
-        else:
-            c2 = ch[f]
-        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
-        m_.np = sum(x.numel() for x in m_.parameters())
-        m_.i, m_.f, m_.type = i, f, mname
+        depth, width, max_ch = scales[d.get("scale") or next(iter(scales))]
+    widths, layers = [], []                  # output channels per node
+    for index, (src, repeats, kind, args) in enumerate(d["backbone"] + d["head"]):
+        cls = _REGISTRY.get(kind)
+        if cls is None:
+            raise NotImplementedError(f"module '{kind}' is outside the Dedark-YOLO hot path (SURVEY.md 8)")
+        row = _Row()
+        row.index, row.src, row.kind, row.nc, row.width, row.max_ch = index, src, kind, nc, width, max_ch
+        row.args = [nc if a == "nc" else _literal(a, ast) for a in args]
+        row.repeats = max(round(repeats * depth), 1) if repeats > 1 else repeats
+        rel = [src] if isinstance(src, int) else list(src)
+        row.ch_in = [(widths[j] if widths else ch) if j == -1 else widths[j] for j in rel]
+        ctor_args, c_out, n_mod = _RULES.get(cls, _PASS_THROUGH)(row)
+        layer = nn.Sequential(*(cls(*ctor_args) for _ in range(n_mod))) if n_mod > 1 else cls(*ctor_args)
+        layer.np = sum(p.numel() for p in layer.parameters())
+        layer.i, layer.f, layer.type = index, src, kind
         if verbose:
-            print(f"{i:>3}{str(f):>20}{n_:>3}{m_.np:10.0f}  {mname:<45}{str(args):<30}")
-        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
-        layers.append(m_)
-        if i == 0:
-            ch = []
-        ch.append(c2)
-    return nn.Sequential(*layers), sorted(save)
+            print(f"{index:>3}{str(src):>20}{row.repeats:>3}{layer.np:10.0f}  {kind:<45}{str(ctor_args):<30}")
+        layers.append(layer)
+        widths.append(c_out)
+    model = nn.Sequential(*layers)
+    return model, GraphPlan(layers).save
+
+
+def _literal(a, ast):
+    if isinstance(a, str):
+        with contextlib.suppress(ValueError, SyntaxError):
+            return ast.literal_eval(a)
+    return a
 
 
 def initialize_weights(model):
@@ -140,16 +188,16 @@ class BaseModel(nn.Module):
             self.current_dedark_A = None
             self.current_IcA = None
         ops.arena.reset()
-        y = []
-        for m in self.model:
-            if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            if isinstance(m, lowlight_recovery) and not self.training:
-                x = m(x, self.current_dedark_A, self.current_IcA)
-            else:
-                x = m(x)
-            y.append(x if m.i in self.save else None)
-        return x
+        plan = self.__dict__.get("_plan")
+        if plan is None or len(plan.nodes) != len(self.model):
+            plan = self.__dict__["_plan"] = GraphPlan(list(self.model))
+        eval_front = not self.training
+
+        def call_layer(m, inp):
+            if eval_front and isinstance(m, lowlight_recovery):
+                return m(inp, self.current_dedark_A, self.current_IcA)
+            return m(inp)
+        return plan.run(x, call_layer)
 
     def loss(self, batch, preds=None):
         if not hasattr(self, "criterion"):
@@ -232,7 +280,7 @@ class DetectionModel(BaseModel):
                 s.append((prev if f == -1 else s[f]) / L.scale_factor)
             elif isinstance(L, Concat):
                 s.append(s[L.i - 1] if f[0] == -1 else s[f[0]])
-            elif isinstance(L, AsffTribeLevel):
+            elif isinstance(L, (AsffTribeLevel, AsffDoubLevel)):
                 s.append(s[f[L.level]])
             elif isinstance(L, Detect):
                 return [float(s[j]) for j in f]

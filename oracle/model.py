@@ -144,6 +144,23 @@ def param_shapes(plan):
             for j in range(3):
                 addconv(p + f"weight_level_{j}.", d, 8, 1)
             plain(p + "weight_levels.", 24, 3, 1)
+        elif kind == "AsffDoubLevel":
+            lv = L["level"]
+            d = (512, 256)[lv]
+            if lv == 0:
+                addconv(p + "stride_level_1.", 256, d, 3)
+                addconv(p + "expand.", d, 512, 3)
+            else:
+                addconv(p + "compress_level_0.", 512, d, 1)
+                addconv(p + "expand.", d, 256, 3)
+            for j in range(2):
+                addconv(p + f"weight_level_{j}.", d, 16, 1)
+            plain(p + "weight_levels.", 32, 2, 1)
+        elif kind == "AsffDetect":
+            for j, cj in enumerate(L["ch"]):
+                plain(p + f"cv2.{j}.0.", cj, 4 * REG_MAX, 1)
+                plain(p + f"cv3.{j}.0.", cj, L["nc"], 1)
+            out[p + "dfl.conv.weight"] = (1, REG_MAX, 1, 1)
         elif kind == "RFBblock":
             c1 = L["c1"]
             q = c1 // 4
@@ -272,6 +289,21 @@ def asff(sd, p, xs, level, train):
     return conv_bn_leaky(sd, p + "expand.", fused, 3, 1, train)
 
 
+def asff2(sd, p, xs, level, train):
+    """AsffDoubLevel.forward (block.py:140-162). xs = (coarse 512-channel map, fine 256-channel map at twice the resolution)."""
+    x0, x1 = xs
+    if level == 0:
+        r0 = x0
+        r1 = conv_bn_leaky(sd, p + "stride_level_1.", x1, 3, 2, train)
+    else:
+        r0 = F.interpolate(conv_bn_leaky(sd, p + "compress_level_0.", x0, 1, 1, train), scale_factor=2, mode="nearest")
+        r1 = x1
+    w = torch.cat([conv_bn_leaky(sd, p + f"weight_level_{j}.", r, 1, 1, train) for j, r in enumerate((r0, r1))], 1)
+    w = F.softmax(F.conv2d(w, sd[p + "weight_levels.weight"], sd[p + "weight_levels.bias"]), dim=1)
+    fused = r0 * w[:, 0:1] + r1 * w[:, 1:2]
+    return conv_bn_leaky(sd, p + "expand.", fused, 3, 1, train)
+
+
 def rfb(sd, p, x):
     """RFBblock.forward (block.py:703-734): 4 branches of biased convs (no BN/act), dilations 1/1/2/3, cat."""
     def cv(name, t, k, pad, dil=1):
@@ -325,6 +357,27 @@ def detect(sd, p, xs, nc, strides, train):
     a = pts.t()[None]                                    # [1,2,A]
     x1y1, x2y2 = a - lt, a + rb
     xywh = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st.t()[None]      # dist2bbox xywh (tal.py:262-271)
+    return torch.cat((xywh, cls.sigmoid()), 1), maps
+
+
+def asff_detect(sd, p, xs, nc, strides, train):
+    """AsffDetect.forward (head.py:128-165): one biased 1x1 conv per branch and level, then Detect's decode."""
+    maps = []
+    for j, x in enumerate(xs):
+        box = F.conv2d(x, sd[p + f"cv2.{j}.0.weight"], sd[p + f"cv2.{j}.0.bias"])
+        cls = F.conv2d(x, sd[p + f"cv3.{j}.0.weight"], sd[p + f"cv3.{j}.0.bias"])
+        maps.append(torch.cat((box, cls), 1))
+    if train:
+        return maps
+    b = maps[0].shape[0]
+    no = 4 * REG_MAX + nc
+    cat = torch.cat([m.view(b, no, -1) for m in maps], 2)
+    box, cls = cat[:, :4 * REG_MAX], cat[:, 4 * REG_MAX:]
+    pts, st = make_anchors([m.shape[2:] for m in maps], strides)
+    d = dfl_expect(box)
+    a = pts.t()[None]
+    x1y1, x2y2 = a - d[:, :2], a + d[:, 2:]
+    xywh = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st.t()[None]
     return torch.cat((xywh, cls.sigmoid()), 1), maps
 
 

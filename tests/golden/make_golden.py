@@ -56,7 +56,7 @@ import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
 from oracle.model import rng_fill  # noqa: E402
-from ultralytics.nn.modules import (C2f, SPPF, Conv, Detect, AsffTribeLevel, RFBblock, lowlight_recovery)  # noqa: E402
+from ultralytics.nn.modules import (C2f, SPPF, Conv, Detect, AsffTribeLevel, AsffDoubLevel, AsffDetect, RFBblock, lowlight_recovery)  # noqa: E402
 from ultralytics.nn.modules.filter_cfg import cfg as filter_cfg  # noqa: E402
 from ultralytics.nn.tasks import DetectionModel, yaml_model_load  # noqa: E402
 from ultralytics.utils.loss import BboxLoss  # noqa: E402
@@ -373,6 +373,23 @@ def g_val():
     save("g6_match", det=det, lab=lab, correct=correct)
 
 
+# ------------------------------------------------------------------ G2b: registry variants
+def g_variants():
+    din = [rnd(31, 1, 512, 3, 4, lo=-1, hi=1), rnd(32, 1, 256, 6, 8, lo=-1, hi=1)]
+    for lv in range(2):
+        run_block(f"g2_asff2_{lv}", AsffDoubLevel(lv), din, 230 + lv, listin=True)
+    det = AsffDetect(5, (16, 32, 32))
+    det.stride = torch.tensor([8., 16., 32.])
+    x = [rnd(33, 2, 16, 8, 8, lo=-1, hi=1), rnd(34, 2, 32, 4, 4, lo=-1, hi=1), rnd(35, 2, 32, 2, 2, lo=-1, hi=1)]
+    run_block("g2_asffdetect_train", det, x, 240, listin=True)
+    det2 = AsffDetect(5, (16, 32, 32))
+    det2.stride = torch.tensor([8., 16., 32.])
+    det2 = fill(set_bn(det2), 240).eval()
+    with torch.no_grad():
+        y, maps = det2([t.clone() for t in x])
+    save("g2_asffdetect_eval", seed=240, x0=x[0], x1=x[1], x2=x[2], y=y, m0=maps[0], m1=maps[1], m2=maps[2])
+
+
 # ------------------------------------------------------------------ G7: a checkpoint exactly as the reference trainer writes it
 def g_ckpt():
     """last.pt of ultralytics/engine/trainer.py:408-433 for a tiny model: pickled half-precision DetectionModel objects under
@@ -449,7 +466,7 @@ def g_pre():
 if __name__ == "__main__":
     which = sys.argv[1:] or None
     todo = dict(frontend=g_frontend, blocks=g_blocks, models=g_models, assigner=g_assigner, small=g_small, val=g_val, ckpt=g_ckpt,
-                pre=g_pre)
+                pre=g_pre, variants=g_variants)
     for k, fn in todo.items():
         if not ONLY or k in ONLY:
             fn()

@@ -86,6 +86,31 @@ def test_asff_golden(level):
     _run_block(f"g2_asff{level}", AsffTribeLevel(level), nin=3, listin=True)
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_asff_two_level_golden(level):
+    from dedark_yolo_amd.nn.modules import AsffDoubLevel
+    _run_block(f"g2_asff2_{level}", AsffDoubLevel(level), nin=2, listin=True)
+
+
+def test_asff_detect_goldens():
+    from dedark_yolo_amd.nn.modules import AsffDetect
+    from parity_helpers import load_sd, set_bn
+    from oracle import model as om
+    d = AsffDetect(5, (16, 32, 32))
+    d.stride = torch.tensor([8., 16., 32.])
+    _run_block("g2_asffdetect_train", d, nin=3, listin=True)
+    g = gold("g2_asffdetect_eval")
+    d = AsffDetect(5, (16, 32, 32))
+    d.stride = torch.tensor([8., 16., 32.])
+    load_sd(set_bn(d), om.rng_fill({k: tuple(v.shape) for k, v in d.state_dict().items()}, int(g["seed"])))
+    d = d.cuda().eval()
+    with torch.no_grad():
+        y, maps = d([g["x0"].cuda(), g["x1"].cuda(), g["x2"].cuda()])
+    close(y.cpu(), g["y"], 1e-4, 1e-4, "asffdetect eval y")
+    for i, m in enumerate(maps):
+        close(m.float().cpu(), g[f"m{i}"], 1e-4, 1e-4, f"asffdetect eval map{i}")
+
+
 def test_detect_train_golden():
     from dedark_yolo_amd.nn.modules import Detect
     d = Detect(5, (16, 32, 32))

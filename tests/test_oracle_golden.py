@@ -107,6 +107,23 @@ def test_asff_golden(level):
            _shapes(dict(kind="AsffTribeLevel", level=level)), nin=3)
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_asff_two_level_golden(level):
+    _block(f"g2_asff2_{level}", lambda sd, x: om.asff2(sd, "", x, level, True), _shapes(dict(kind="AsffDoubLevel", level=level)), nin=2)
+
+
+def test_asff_detect_goldens():
+    sh = _shapes(dict(kind="AsffDetect", nc=5, ch=[16, 32, 32]))
+    _block("g2_asffdetect_train", lambda sd, x: om.asff_detect(sd, "", x, 5, [8., 16., 32.], True), sh, nin=3)
+    g = gold("g2_asffdetect_eval")
+    sd = om.rng_fill(sh, int(g["seed"]))
+    with torch.no_grad():
+        y, maps = om.asff_detect(sd, "", [g["x0"], g["x1"], g["x2"]], 5, [8., 16., 32.], False)
+    close(y, g["y"], 1e-4, 1e-4, "asffdetect eval y")
+    for i, m in enumerate(maps):
+        close(m, g[f"m{i}"], 1e-4, 1e-4, f"asffdetect eval map{i}")
+
+
 def test_detect_goldens():
     sh = _shapes(dict(kind="Detect", nc=5, ch=[16, 32, 32]))
     _block("g2_detect_train", lambda sd, x: om.detect(sd, "", x, 5, [8., 16., 32.], True), sh, nin=3)
