@@ -208,12 +208,31 @@ class BaseModel(nn.Module):
     def init_criterion(self):
         raise NotImplementedError
 
+    def _bn_pairs(self):
+        import torch.nn as nn_
+        for m in self.modules():
+            bn = getattr(m, "bn", None) or getattr(m, "batch_norm", None)
+            conv = getattr(m, "conv", None)
+            if isinstance(bn, nn_.BatchNorm2d) and isinstance(conv, nn_.Conv2d):
+                yield conv, bn
+
     def fuse(self, verbose=True):
-        """The HIP conv folds BatchNorm into its epilogue at call time in eval mode; nothing to rewrite."""
+        """reference tasks.py:153-178 / fuse_conv_and_bn (torch_utils.py:123-144).  The HIP conv applies BatchNorm as a per-channel
+        affine in its epilogue, so fusing = computing that affine once: every Conv / add_conv gets its folded (scale, shift) cached
+        and the eval forward launches no fold kernel afterwards.  The parameters stay untouched (training can continue; the caches
+        are invalidated by any weight or buffer update)."""
+        n = 0
+        for conv, bn in self._bn_pairs():
+            if bn.weight.is_cuda:
+                ops.bn_fold(bn, ops.round_up(conv.out_channels, ops.vec_elems(ops.get_compute_dtype())))
+                n += 1
+        if verbose and n == 0:
+            print("fuse(): move the model to the GPU first (the folded affines live next to the weights)")
         return self
 
     def is_fused(self, thresh=10):
-        return False
+        pairs = list(self._bn_pairs())
+        return bool(pairs) and all(ops.bn_fold_is_current(bn) for _, bn in pairs)
 
     def load(self, weights, verbose=True):
         """reference tasks.py:222-234: intersect by name and shape, non-strict load."""

@@ -292,6 +292,29 @@ def _padded_vec(v, n):
 
 
 # ------------------------------------------------------------------------------------------------ conv + bn + act
+def bn_fold(bn, cout_pad):
+    """scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale as a cached [2, cout_pad] f32 tensor on the
+    BatchNorm module.  The fold is recomputed only when a weight or buffer changed (optimizer step, load_state_dict, a training
+    forward): `BaseModel.fuse()` fills every cache up front, afterwards an eval forward launches no fold kernel at all."""
+    tag = (_weights_epoch, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr(), cout_pad)
+    hit = bn.__dict__.get("_dy_fold")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    aff = hit[1] if (hit is not None and hit[1].shape[1] == cout_pad and hit[1].device == bn.weight.device) else \
+        torch.empty((2, cout_pad), dtype=torch.float32, device=bn.weight.device)
+    call("dy_bn_fold_eval", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps),
+         ptr(aff[0]), ptr(aff[1]), cout_pad, stream())
+    bn.__dict__["_dy_fold"] = (tag, aff)
+    return aff
+
+
+def bn_fold_is_current(bn):
+    hit = bn.__dict__.get("_dy_fold")
+    return hit is not None and hit[0][:7] == (_weights_epoch, bn.weight._version, bn.bias._version, bn.running_mean._version,
+                                               bn.running_var._version, bn.weight.data_ptr(), bn.running_mean.data_ptr())
+
+
 class ConvCtx:
     __slots__ = ("x", "z", "aff", "weight", "bias", "bn", "act", "k", "stride", "pad", "dil", "cout", "cout_pad", "cin_pad",
                  "has_bn", "y", "owner")
@@ -356,6 +379,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         pa, sa = aff.data_ptr(), 4 * cout_pad
         pixels = B * Ho * Wo
         _bn_pending[bn] = _bn_pending.get(bn, 0) + 1
+        bn.__dict__.pop("_dy_fold", None)          # the kernels below rewrite the running statistics through raw pointers
         y = out if out is not None else empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
         st = stream()
         rp, rld = (residual.data_ptr(), ld_of(residual)) if residual is not None else (None, 0)
@@ -376,10 +400,8 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         if ctx is not None:
             ctx.z, ctx.aff, ctx.y = z, aff, None
     else:
-        if has_bn:                      # eval: fold running statistics
-            aff = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
-            call("dy_bn_fold_eval", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps),
-                 ptr(aff[0]), ptr(aff[1]), cout_pad, stream())
+        if has_bn:                      # eval: running statistics folded into the conv epilogue (fuse_conv_and_bn, torch_utils.py:123-144)
+            aff = bn_fold(bn, cout_pad)
             scale, shift = aff[0], aff[1]
         else:
             scale, shift = None, _padded_vec(bias, cout_pad)

@@ -253,3 +253,47 @@ def test_nms_candidate_stage_vs_reference_fixture():
             want = z[f"{tag}_out{i}"]
             assert int(cnt[i]) == want.shape[0], (tag, i, int(cnt[i]), want.shape[0])
             assert np.array_equal(rows(out[i, :want.shape[0]].cpu()), rows(want)), (tag, i)
+
+
+def test_fuse_caches_the_batchnorm_fold():
+    """BaseModel.fuse(): the eval-mode BatchNorm fold of every Conv is computed once and cached; outputs are unchanged, a training
+    step invalidates the caches, the next eval forward rebuilds them (reference fuse_conv_and_bn, torch_utils.py:123-144)."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd import _C
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from util import load_yaml
+    dy.set_compute_dtype(torch.float32)
+    cfg = load_yaml("yolov8ori.yaml")
+    cfg["scales"]["t"] = [0.33, 0.125, 1024]
+    cfg["scale"] = "t"
+    torch.manual_seed(3)
+    m = DetectionModel(cfg, nc=6).cuda().eval()
+    for b in m.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.uniform_(-0.2, 0.2)
+            b.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    assert not m.is_fused()
+    with torch.no_grad():
+        y0 = m(x)[0].clone()
+    assert m.is_fused()                              # the first eval forward filled the caches
+    calls = []
+    orig = _C.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    import dedark_yolo_amd.ops as ops
+    ops.call = spy
+    try:
+        with torch.no_grad():
+            y1 = m(x)[0]
+    finally:
+        ops.call = orig
+    assert "dy_bn_fold_eval" not in calls and torch.equal(y0, y1)
+    ops.bump_weights_epoch()                          # what an optimizer step does
+    assert not m.is_fused()
+    m.fuse()
+    assert m.is_fused()
+    with torch.no_grad():
+        assert torch.equal(m(x)[0], y0)
