@@ -21,6 +21,8 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d);
 int dy_conv_v2_launch(const dy_conv_desc* d, int mode, void* stream);
 int dy_conv_v2_launch_classes(const dy_conv_desc* classes, int ncls, void* stream);
 // band kernel for 3x3 / stride-1 bf16 convs (conv_v3.hip)
+bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode);
+int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream);
 bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode);
 int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream);
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
@@ -932,6 +934,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
   if (dy_dense_fwd_eligible(d)) return dy_dense_fwd_launch(d, stream);
   if (dy_conv_v4_eligible(d, 0)) return dy_conv_v4_launch(d, 0, stream);
+  if (dy_conv_v5_eligible(d, 0)) return dy_conv_v5_launch(d, 0, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
@@ -1016,6 +1019,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
         const dy_conv_desc* q = &c[i];
         int e;
         if (dy_conv_v4_eligible(q, 0)) e = dy_conv_v4_launch(q, 0, stream);
+        else if (dy_conv_v5_eligible(q, 0)) e = dy_conv_v5_launch(q, 0, stream);
         else if (dy_conv_v2_eligible(q)) e = dy_conv_v2_launch(q, 0, stream);
         else e = q->dtype == DY_F32 ? launch_conv<float, 0>(q, (hipStream_t)stream) : launch_conv<bf16_t, 0>(q, (hipStream_t)stream);
         if (e) return e;
@@ -1024,6 +1028,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
     }
   }
   if (dy_conv_v4_eligible(d, 1)) return dy_conv_v4_launch(d, 1, stream);
+  if (dy_conv_v5_eligible(d, 1)) return dy_conv_v5_launch(d, 1, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;

@@ -85,14 +85,17 @@ constexpr int row_image_bytes() { return BM * row_pitch<BN>(); }
 template <int BM, int BN, int NW, typename OffFn>
 __device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, bf16_t* dst, OffFn off) {
   constexpr int PT = row_pitch<BN>();
-  constexpr int ITERS = BM / 4 / NW;               // 4 pixels per wave instruction
-  const int pl = lane >> 4, chunk = lane & 15;
+  constexpr int LPP = BN >= 128 ? 16 : BN / 8;      // lanes (16-byte chunks) per pixel and instruction: 16 (256 B) or 8 (BN = 64: 128 B)
+  constexpr int PPI = 64 / LPP;                     // pixels per wave instruction
+  constexpr int ITERS = BM / PPI / NW;
+  constexpr int HALVES = BN >= 128 ? BN / 128 : 1;
+  const int pl = lane / LPP, chunk = lane % LPP;
 #pragma unroll 2
   for (int u = 0; u < ITERS; ++u) {
-    const int px = 4 * (wave + NW * u) + pl;
+    const int px = PPI * (wave + NW * u) + pl;
     const long m = m0 + px;
 #pragma unroll
-    for (int h = 0; h < BN / 128; ++h) {
+    for (int h = 0; h < HALVES; ++h) {
       const int c = 128 * h + 8 * chunk;
       const uint2 lo = *reinterpret_cast<const uint2*>(smem + px * PT + c * 2);
       const uint2 hi = *reinterpret_cast<const uint2*>(smem + px * PT + c * 2 + 8);

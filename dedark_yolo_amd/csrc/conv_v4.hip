@@ -77,7 +77,8 @@ __device__ inline long dst_offset(const P& p, long m) {
 }
 
 // ABL: compile-time ablation mask for tools/v4_diag (the library only instantiates ABL = 0): 1 no DMA inside the loop, 2 no MFMA,
-// 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores.
+// 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores,
+// 128 no s_setprio around the MFMA clusters, 128 + 256 priority to the loading wave instead.
 template <int ABL>
 __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,19 +204,23 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
       bfr[h][j][1] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + (b_rd ^ 64) + 2048 * j);
     }
   };
-  auto mma = [&](int ah, int bh) {
+  // `mid` runs between the two k-halves of the cluster: with ABL & 1024 the phase's DMA is issued there (experiment: the DMA issue
+  // then waits on this wave's own matrix pipe instead of lengthening the load part the partner wave is waiting for)
+  auto mma = [&](int ah, int bh, auto mid) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ABL & 256) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
 #pragma unroll
       for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[bh][j][0])); asm volatile("" ::"v"(bfr[bh][j][1])); }
+      mid();
       return;
     }
-    __builtin_amdgcn_s_setprio(1);
+    if (!(ABL & 128)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -223,9 +228,18 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
           // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
           acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[bh][j][kb]),
                                                                        __builtin_bit_cast(bf16x8, afr[i][kb]), acc[ah][bh][i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+      if (kb == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(ABL & 128)) __builtin_amdgcn_s_setprio(0);
+    if (ABL & 256) __builtin_amdgcn_s_setprio(1);       // (experiment: the loading wave gets the priority)
     __builtin_amdgcn_sched_barrier(0);
   };
+  constexpr bool DMA_MID = (ABL & 1024) != 0;
+  auto nothing = []() {};
 
   // ---- prologue: K-step 0 complete + three half-tiles of K-step 1 in flight
   stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
@@ -236,48 +250,86 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   if (!(ABL & 8) && wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
   in_loop = true;
 
+  // ABL & 512 (tools/v4_diag only): s_memtime stamps at the three points of a phase where no LDS read is in flight -- phase start,
+  // after the first barrier + lgkmcnt(0), after the MFMA cluster -- summed per phase over the K-loop; lane 0 of waves 0 and 4 of
+  // block 0 write the sums to the buffer passed as `stats`.
+  unsigned long long t_sum[4][3] = {};
+  unsigned long long t_prev = 0;
+  auto stamp = [&](int ph, int which) {
+    if (!(ABL & 512)) return;
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (which >= 0) t_sum[ph][which] += t - t_prev;
+    t_prev = t;
+  };
   auto kstep = [&](auto bufc) {
     constexpr int b = decltype(bufc)::value;
     // P1
+    stamp(3, 2);                                   // (closes the previous phase: second barrier of P4)
     read_b(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
-    stage_a(b ^ 1, 1);
-    advance();
+    if (!DMA_MID) { stage_a(b ^ 1, 1); advance(); }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B reads (issued first) are back: B-half 0 may be refilled in P2
     __builtin_amdgcn_s_barrier();
-    mma(0, 0);
+    stamp(0, 0);
+    if (DMA_MID) mma(0, 0, [&]() { stage_a(b ^ 1, 1); advance(); });
+    else mma(0, 0, nothing);
+    stamp(0, 1);
     __builtin_amdgcn_s_barrier();
     // P2
+    stamp(0, 2);
     read_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    stage_b(b, 0);
+    if (!DMA_MID) stage_b(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(0, 1);
+    stamp(1, 0);
+    if (DMA_MID) mma(0, 1, [&]() { stage_b(b, 0); });
+    else mma(0, 1, nothing);
+    stamp(1, 1);
     __builtin_amdgcn_s_barrier();
     // P3
+    stamp(1, 2);
     read_a(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    stage_a(b, 0);
+    if (!DMA_MID) stage_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(1, 1);
+    stamp(2, 0);
+    if (DMA_MID) mma(1, 1, [&]() { stage_a(b, 0); });
+    else mma(1, 1, nothing);
+    stamp(2, 1);
     __builtin_amdgcn_s_barrier();
     // P4
-    stage_b(b, 1);
+    stamp(2, 2);
+    if (!DMA_MID) stage_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // everything but the three youngest half-tiles: K-step k+1 is complete
+    // everything but the three youngest half-tiles: K-step k+1 is complete (DMA_MID: this phase's refill is issued after the wait,
+    // so only TWO half-tiles are younger than K-step k+1's last one)
+    if (DMA_MID) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    mma(1, 0);
+    stamp(3, 0);
+    if (DMA_MID) mma(1, 0, [&]() { stage_b(b, 1); });
+    else mma(1, 0, nothing);
+    stamp(3, 1);
     __builtin_amdgcn_s_barrier();
   };
 
+  stamp(0, -1);
   for (int kt = 0; kt < p.nk; kt += 2) {
     kstep(std::integral_constant<int, 0>{});
     if (kt + 1 < p.nk) kstep(std::integral_constant<int, 1>{});
+  }
+  if ((ABL & 512) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + (wave ? 12 : 0);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 3; ++j) o[3 * i + j] = t_sum[i][j];
   }
   if (!(ABL & 8) && wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero fills of the steps beyond the last one have landed
@@ -330,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   if (!(ABL & 64))
     dy_epi::store_rows<BM, BN, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
                                   [&](long m) { return dst_offset(p, m); });
-  if (p.stats) {
+  if (p.stats && !(ABL & 512)) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);        // [2 (wr)][BN][2]
 #pragma unroll
@@ -365,282 +417,11 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// 256 x 128 tile for the layers with <= 128 output channels per tile (128->128 3x3 at 80x80, the 1x1 layers with 128 / 320 / 384
-// outputs): same staggered two-group structure, wave tile 64 x 64 on 4 (M) x 2 (N) waves, a K-step = 2 phases of 16 MFMAs
-// (A-half 0 x B, A-half 1 x B) and THREE units of DMA (B, A-half 0, A-half 1).  48 KiB per K-step allows a ring of three
-// buffers, so every unit is refilled two K-steps ahead of its use and exactly two phases after its last read: no early-retire
-// counts are needed; one s_waitcnt vmcnt(6) per K-step (P2) leaves the three youngest units in flight.
-constexpr int N1_BUF = 3 * HALF;                    // A-half 0, A-half 1, B
-
-template <int ABL>
-__global__ __launch_bounds__(512) void conv_kernel_n128(const P p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;            // wn is also the stagger group (waves w and w + 4 share a SIMD)
-  const int bid = xcd_remap(blockIdx.x, p.nblk);
-  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const long m0 = (long)tile_m * 256;
-  const int n0 = tile_n * 128;
-
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-
-  const int lrow = lane >> 3, slot = lane & 7;
-  const int chunk = slot ^ ((4 * wave + (lane >> 4)) & 7);
-  unsigned a_off[4], a_mask[4], b_off[2];
-  {
-    const long HWd = (long)p.Hd * p.Wd;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
-      const long m = m0 + r;
-      const bool ok = m < p.M;
-      const unsigned mm = ok ? (unsigned)m : 0u;           // M < 2^31 (checked by the launcher): 32-bit divisions
-      const int img = (int)(mm / (unsigned)HWd);
-      const int rem = (int)(mm - (unsigned)img * (unsigned)HWd);
-      const int oh = (int)((unsigned)rem / (unsigned)p.Wd), ow = rem - oh * p.Wd;
-      const int sh0 = oh * p.stride, sw0 = ow * p.stride;
-      a_off[i] = (unsigned)((((long)img * p.Hs + sh0) * p.Ws + sw0) * p.src_ld * 2 + chunk * 16);
-      unsigned mk = 0;
-      int bit = 0;
-      for (int th = 0; th < p.KH; ++th) {
-        const int sh = sh0 + p.dh0 + p.dhs * th;
-        for (int tw = 0; tw < p.KW; ++tw, ++bit) {
-          const int sw = sw0 + p.dw0 + p.dws * tw;
-          if (ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws) mk |= 1u << bit;
-        }
-      }
-      a_mask[i] = mk;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 8 * (wave + 8 * j) + lrow;
-      b_off[j] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
-    }
-  }
-  int sk = 0, s_th = 0, s_tw = 0, s_ci = 0, s_bit = 0;
-  int a_koff = (p.dh0 * p.Ws + p.dw0) * (int)p.src_ld * 2;
-  unsigned b_koff = (unsigned)(((long)(p.kh0 * p.KWf + p.kw0)) * p.Cs * 2);
-  auto advance = [&]() {
-    ++sk;
-    s_ci += BK;
-    a_koff += BK * 2;
-    b_koff += BK * 2;
-    if (s_ci >= p.Cs) {
-      s_ci = 0;
-      ++s_bit;
-      if (++s_tw == p.KW) { s_tw = 0; ++s_th; }
-      a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2;
-      b_koff = (unsigned)(((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs * 2);
-    }
-    if (sk >= p.nk) {
-      s_bit = 31;
-      b_koff = 0x80000000u;
-    }
-  };
-  if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
-  bool in_loop = false;
-  auto stage_a = [&](int base, int h) {
-    if ((ABL & 1) && in_loop) return;
-    if (ABL & 16) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = 2 * h + j;
-      const unsigned v = ((a_mask[i] >> s_bit) & 1u) ? a_off[i] + (unsigned)a_koff : A_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + h * HALF + (wave + 8 * j) * 1024), 16, (int)v, 0, 0, 0);
-    }
-  };
-  auto stage_b = [&](int base) {
-    if ((ABL & 1) && in_loop) return;
-    if (ABL & 32) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + 2 * HALF + (wave + 8 * j) * 1024), 16,
-                                               (int)(b_off[j] + b_koff), 0, 0, 0);
-  };
-
-  const int fr = lane & 15, fq = lane >> 4, key = (fr >> 1) & 7;
-  const int off0 = ((((key >> 2) << 2) | ((fq ^ key) & 3)) << 4);
-  const int a_rd = (32 * wm + fr) * 128 + off0;
-  const int b_rd = 2 * HALF + (64 * wn + fr) * 128 + off0;
-
-  f32x4 acc[2][2][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 afr[2][2], bfr[4][2];
-  auto rd = [&](int byte) {
-    if (ABL & 4) return u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    return *reinterpret_cast<const u32x4*>(smem + byte);
-  };
-  auto read_a = [&](int base, int h) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      afr[i][0] = rd(base + h * HALF + a_rd + 2048 * i);
-      afr[i][1] = rd(base + h * HALF + (a_rd ^ 64) + 2048 * i);
-    }
-  };
-  auto read_b = [&](int base) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bfr[j][0] = rd(base + b_rd + 2048 * j);
-      bfr[j][1] = rd(base + (b_rd ^ 64) + 2048 * j);
-    }
-  };
-  auto mma = [&](int h) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (ABL & 2) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(bfr[j][0])); asm volatile("" ::"v"(bfr[j][1])); }
-      return;
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[h][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j][kb]), __builtin_bit_cast(bf16x8, afr[i][kb]),
-                                                                  acc[h][i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- prologue: K-steps 0 and 1 issued, K-step 0 landed
-  stage_b(0); stage_a(0, 0); stage_a(0, 1);
-  advance();
-  stage_b(N1_BUF); stage_a(N1_BUF, 0); stage_a(N1_BUF, 1);
-  advance();
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (!(ABL & 8) && wn == 1) __builtin_amdgcn_s_barrier();
-  in_loop = true;
-
-  int cur = 0, fill = 2 * N1_BUF;                    // byte base of the buffer being computed / refilled (K-step kt + 2)
-  for (int kt = 0; kt < p.nk; ++kt) {
-    // P1
-    read_b(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_b(fill);
-    stage_a(fill, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    mma(0);
-    __builtin_amdgcn_s_barrier();
-    // P2
-    read_a(cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_a(fill, 1);
-    advance();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-step kt + 1 is complete; the three units of kt + 2 stay in flight
-    __builtin_amdgcn_s_barrier();
-    mma(1);
-    __builtin_amdgcn_s_barrier();
-    cur = cur == 2 * N1_BUF ? 0 : cur + N1_BUF;
-    fill = fill == 2 * N1_BUF ? 0 : fill + N1_BUF;
-  }
-  if (!(ABL & 8) && wn == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue (as above; 128 channels per pixel row)
-  constexpr int PT = dy_epi::row_pitch<128>();
-  const int cl = lane & 15, g = lane >> 4;
-  float csum[4][4], csq[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c0 = 64 * wn + 16 * j + 4 * g;
-    float sc[4], sf[4];
-    bool nok[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = n0 + c0 + e;
-      nok[e] = n < p.Cd;
-      sc[e] = (nok[e] && p.scale) ? p.scale[n] : 1.f;
-      sf[e] = (nok[e] && p.shift) ? p.shift[n] : 0.f;
-      csum[j][e] = 0.f;
-      csq[j][e] = 0.f;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int px = 128 * h + 32 * wm + 16 * i + cl;
-        const bool mok = m0 + px < p.M;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = acc[h][i][j][e];
-          if (mok && nok[e]) {
-            csum[j][e] += a;
-            csq[j][e] += a * a;
-          }
-          float u = a * sc[e] + sf[e];
-          if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
-          else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
-          v[e] = u;
-        }
-        uint2 w2 = {dy_epi::pack2(v[0], v[1]), dy_epi::pack2(v[2], v[3])};
-        *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
-      }
-  }
-  __syncthreads();
-  if (!(ABL & 64))
-    dy_epi::store_rows<256, 128, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
-                                    [&](long m) { return dst_offset(p, m); });
-  if (p.stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);        // [4 (wm)][128][2]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s1 = csum[j][e], s2 = csq[j][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
-        if (cl == 0) {
-          const int col = 64 * wn + 16 * j + 4 * g + e;
-          red[(wm * 128 + col) * 2] = s1;
-          red[(wm * 128 + col) * 2 + 1] = s2;
-        }
-      }
-    __syncthreads();
-    if (tid < 128) {
-      const int n = n0 + tid;
-      if (n < p.Cd) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          s1 += red[(w * 128 + tid) * 2];
-          s2 += red[(w * 128 + tid) * 2 + 1];
-        }
-        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
-        atomic_add_f64(st + n, (double)s1);
-        atomic_add_f64(st + p.Cd + n, (double)s2);
-      }
-    }
-  }
-}
-
 }  // namespace v4
 
-// Tile variant for a problem: 256 (x 256 tile) when the 256-wide channel tiles carry <= 20 % padding, else 128 (x 256 x 128 tile)
-// under the same rule, else 0 (not taken).  One block per CU: only worth it when the tiles fill most of the chip.
+// Taken when the 256-wide channel tiles carry <= 20 % padding, the reduction is long enough to amortise the 128 KiB epilogue of a
+// tile (K >= 512; shorter ones and the narrower layers go to conv_v5.hip, two smaller blocks per CU) and the tiles fill most of
+// the chip (one block per CU).
 static int v4_variant(const dy_conv_desc* d, int mode) {
   if (d->dtype != DY_BF16) return 0;
   if (!(d->Cs % 64 == 0 && d->KH * d->KW <= 25)) return 0;
@@ -651,9 +432,8 @@ static int v4_variant(const dy_conv_desc* d, int mode) {
   const long w_bytes = (long)d->Cd * w_row * 2;
   if (!(src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return 0;
   const long tiles_m = ((long)d->N * d->Hd * d->Wd + 255) / 256;
-  const long t256 = (d->Cd + 255) / 256, t128 = (d->Cd + 127) / 128;
-  if (d->Cd >= 192 && t256 * 256 * 4 <= (long)d->Cd * 5 && tiles_m * t256 >= 192) return 256;
-  if (d->Cd >= 96 && t128 * 128 * 4 <= (long)d->Cd * 5 && tiles_m * t128 >= 192) return 128;
+  const long t256 = (d->Cd + 255) / 256;
+  if (d->Cd >= 192 && t256 * 256 * 4 <= (long)d->Cd * 5 && tiles_m * t256 >= 192 && (long)d->KH * d->KW * d->Cs >= 512) return 256;
   return 0;
 }
 
@@ -697,26 +477,19 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
   p.tiles_n = dy_cdiv(d->Cd, variant);
   p.nblk = dy_cdiv(p.M, v4::BM) * p.tiles_n;
   constexpr int EPI256 = dy_epi::row_image_bytes<256, 256>();
-  constexpr int SH256 = 2 * v4::BUF > EPI256 ? 2 * v4::BUF : EPI256, SH128 = 3 * v4::N1_BUF;
-  static_assert(SH256 <= 160 * 1024 && SH128 <= 160 * 1024 && SH128 >= dy_epi::row_image_bytes<256, 128>(), "LDS budget");
+  constexpr int SH256 = 2 * v4::BUF > EPI256 ? 2 * v4::BUF : EPI256;
+  static_assert(SH256 <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4::conv_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, SH256);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4::conv_kernel_n128<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
     if (e != hipSuccess) {
       dy_set_error("conv_v4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
     }
     configured = true;
   }
-  if (variant == 256) {
-    dy_note_kernel("v4::conv_kernel");
-    v4::conv_kernel<ABL><<<p.nblk, 512, SH256, (hipStream_t)stream>>>(p);
-  } else {
-    dy_note_kernel("v4::conv_kernel_n128");
-    v4::conv_kernel_n128<ABL><<<p.nblk, 512, SH128, (hipStream_t)stream>>>(p);
-  }
+  dy_note_kernel("v4::conv_kernel");
+  v4::conv_kernel<ABL><<<p.nblk, 512, SH256, (hipStream_t)stream>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
 }

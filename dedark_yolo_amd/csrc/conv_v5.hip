@@ -1,0 +1,345 @@
+// Two-blocks-per-CU implicit-GEMM convolution for the wide bf16 layers: forward and stride-1 data gradient of nn.Conv2d inside Conv /
+// Bottleneck / Detect (ultralytics/nn/modules/conv.py:38-55, block.py:553-565, head.py:40-46).
+//
+// conv_v4.hip (one 8-wave block per CU, two wave groups one barrier apart) reaches the MFMA rate of the CDNA4 playbook's best GEMM
+// loop, but a conv layer is a short GEMM: 18-36 K-steps per tile, then 64-128 KiB of output.  tools/v4_diag measured what that costs
+// with one block per CU: all 256 CUs reach their epilogues together, the store burst (33 MB) runs at the HBM write rate while every
+// MFMA pipe idles (12-15 us of a 70 us tile), then every block pays its address set-up and first DMA round trip, and 400 tiles on 256
+// CUs leave the second round half empty.  This kernel keeps the per-wave work of v4 (128 x 64 wave tile, v_mfma_f32_16x16x32_bf16,
+// transposed product so that a lane holds 4 consecutive output channels, LDS-DMA with out-of-range offsets for padding) and changes
+// the block shape so that TWO blocks share a CU:
+//   * 256 x 128 tile on 4 waves (2 x 2), K-step 32: 24 KiB per stage, three stages = 72 KiB per block, 256 VGPRs per wave;
+//   * one barrier per K-step: wait (counted vmcnt: the next stage stays in flight) -> barrier -> refill the stage two steps ahead ->
+//     12 x ds_read_b128 + 32 MFMAs;
+//   * the two blocks of a CU are independent: one block's epilogue, set-up and barrier waits overlap the other block's K-loop, and
+//     tiles are handed out at twice the granularity (the tail round costs half as much).
+// LDS rows are 64 bytes (32 bf16); 16-byte slot s of row r holds chunk s ^ (((r >> 2) & 2) ? 3 : 0): the four 16-lane groups of a
+// ds_read_b128 (16x16x32 operand: lane = row l&15, chunk l>>4) then hit 16 different slots of the 256-byte bank row.
+#include <stdlib.h>
+#include "dy_common.h"
+#include "conv_epilogue.h"
+#include "../../include/dedark_yolo.h"
+
+namespace v5 {
+
+constexpr int BM = 256, BK = 32;
+constexpr int A_BYTES = BM * 64, NSTAGE = 3;
+constexpr unsigned A_OOB = 0x80000000u;             // > any source extent (checked by the dispatcher: <= 2 GiB)
+constexpr unsigned B_ROW_OOB = 0x40000000u;         // weight extent <= 1 GiB: row-invalid + any k offset stays out of range
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct P {
+  const char* src;
+  const char* w;
+  char* dst;
+  unsigned src_bytes, w_bytes;
+  long src_ld, dst_ld, dst_row, dst_img;
+  int Hs, Ws, Cs, Hd, Wd, Cd;
+  int stride;
+  int KH, KW;
+  int dh0, dhs, dw0, dws;        // window tap (th, tw) reads source pixel (oh*stride + dh0 + dhs*th, ow*stride + dw0 + dws*tw)
+  int kh0, khs, kw0, kws, KWf;   // ... and weight tap (kh0 + khs*th, kw0 + kws*tw) of a KHf x KWf pack
+  long w_row;                    // elements per output-channel row of the weight pack
+  const float* scale;
+  const float* shift;
+  int act;
+  double* stats;
+  int accumulate;
+  long M;
+  int nk;                        // K-steps = KH*KW*Cs/32
+  int tiles_n, nblk;
+};
+
+__device__ inline int xcd_remap(int bid, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ inline long dst_offset(const P& p, long m) {
+  if (p.dst_row == 0) return m * p.dst_ld;
+  const long HWd = (long)p.Hd * p.Wd;
+  const long img = m / HWd;
+  const int rem = (int)(m - img * HWd);
+  const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+  return img * p.dst_img + (long)oh * p.dst_row + (long)ow * p.dst_ld;
+}
+
+// BN = 128: waves 2 (M) x 2 (N), wave tile 128 x 64.  BN = 64 (the 64-channel layers): waves 4 x 1, wave tile 64 x 64.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
+  constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, NB = 4, STAGE = A_BYTES + BN * 64, B_LD = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills rows 16*idx .. +15 of the A (j < 4) / B (j < 2) tile
+  const int lrow = lane >> 2, slot = lane & 3;
+  const int chunk = slot ^ ((lane & 32) ? 3 : 0);          // logical 16-byte chunk (8 channels of the 32-deep step) this lane fetches
+  unsigned a_off[4], a_mask[4], b_off[B_LD];
+  {
+    const unsigned HWd = (unsigned)(p.Hd * p.Wd);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 16 * (wave + 4 * j) + lrow;
+      const long m = m0 + r;
+      const bool ok = m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;           // M < 2^31 (checked by the launcher): 32-bit divisions
+      const int img = (int)(mm / HWd);
+      const int rem = (int)(mm - (unsigned)img * HWd);
+      const int oh = (int)((unsigned)rem / (unsigned)p.Wd), ow = rem - oh * p.Wd;
+      const int sh0 = oh * p.stride, sw0 = ow * p.stride;
+      a_off[j] = (unsigned)((((long)img * p.Hs + sh0) * p.Ws + sw0) * p.src_ld * 2 + chunk * 16);
+      unsigned mk = 0;
+      int bit = 0;
+      for (int th = 0; th < p.KH; ++th) {
+        const int sh = sh0 + p.dh0 + p.dhs * th;
+        for (int tw = 0; tw < p.KW; ++tw, ++bit) {
+          const int sw = sw0 + p.dw0 + p.dws * tw;
+          if (ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws) mk |= 1u << bit;
+        }
+      }
+      a_mask[j] = mk;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int n = n0 + 16 * (wave + 4 * j) + lrow;
+      b_off[j] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
+    }
+  }
+  // K-step being issued (wave-uniform)
+  int sk = 0, s_th = 0, s_tw = 0, s_ci = 0, s_bit = 0;
+  int a_koff = (p.dh0 * p.Ws + p.dw0) * (int)p.src_ld * 2;
+  unsigned b_koff = (unsigned)(((long)(p.kh0 * p.KWf + p.kw0)) * p.Cs * 2);
+  if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
+  auto advance = [&]() {
+    ++sk;
+    s_ci += BK;
+    a_koff += BK * 2;
+    b_koff += BK * 2;
+    if (s_ci >= p.Cs) {
+      s_ci = 0;
+      ++s_bit;
+      if (++s_tw == p.KW) { s_tw = 0; ++s_th; }
+      a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2;
+      b_koff = (unsigned)(((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs * 2);
+    }
+    if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a stage nobody reads again)
+      s_bit = 31;
+      b_koff = 0x80000000u;
+    }
+  };
+  auto issue = [&](int base) {                 // one stage: 4 + 2 DMA instructions per wave, ONE unconditional load per lane each
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned v = ((a_mask[j] >> s_bit) & 1u) ? a_off[j] + (unsigned)a_koff : A_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)v, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + A_BYTES + (wave + 4 * j) * 1024), 16,
+                                               (int)(b_off[j] + b_koff), 0, 0, 0);
+    advance();
+  };
+
+  // ---- fragment read addresses (16x16x32 operand: lane = row l&15, chunk l>>4)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fq ^ ((fr & 8) ? 3 : 0)) * 16;
+  const int a_rd = (16 * MB * wm + fr) * 64 + sw;        // + 1024 * m-block
+  const int b_rd = A_BYTES + (64 * wn + fr) * 64 + sw;   // + 1024 * n-block
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  issue(STAGE);
+  int cur = 0, fill = 2 * STAGE;
+  for (int kt = 0; kt < p.nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + B_LD) : "memory");      // everything but the youngest stage: K-step kt has landed
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; and every wave is done reading K-step kt - 1
+    __builtin_amdgcn_sched_barrier(0);
+    issue(fill);                                           // K-step kt + 2 into the stage K-step kt - 1 occupied
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 bfr[NB], afr[MB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + cur + b_rd + 1024 * j);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) afr[i] = *reinterpret_cast<const u32x4*>(smem + cur + a_rd + 1024 * i);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]), __builtin_bit_cast(bf16x8, afr[i]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = cur == 2 * STAGE ? 0 : cur + STAGE;
+    fill = fill == 2 * STAGE ? 0 : fill + STAGE;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills of the steps beyond the last one have landed
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: bf16 image [pixel][channel] (conv_epilogue.h: store_rows) -> 16-byte stores, 256 contiguous bytes per quarter-wave
+  constexpr int PT = dy_epi::row_pitch<BN>();
+  const int cl = lane & 15, g = lane >> 4;
+  float csum[4][4], csq[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c0 = 64 * wn + 16 * j + 4 * g;               // this lane's 4 channels of the block
+    float sc[4], sf[4];
+    bool nok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + c0 + e;
+      nok[e] = n < p.Cd;
+      sc[e] = (nok[e] && p.scale) ? p.scale[n] : 1.f;
+      sf[e] = (nok[e] && p.shift) ? p.shift[n] : 0.f;
+      csum[j][e] = 0.f;
+      csq[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int px = 16 * MB * wm + 16 * i + cl;
+      const bool mok = m0 + px < p.M;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = acc[i][j][e];
+        if (mok && nok[e]) {
+          csum[j][e] += a;
+          csq[j][e] += a * a;
+        }
+        float u = a * sc[e] + sf[e];
+        if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
+        else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
+        v[e] = u;
+      }
+      uint2 w2 = {dy_epi::pack2(v[0], v[1]), dy_epi::pack2(v[2], v[3])};
+      *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
+    }
+  }
+  __syncthreads();
+  dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
+                                [&](long m) { return dst_offset(p, m); });
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = csum[j][e], s2 = csq[j][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {                 // over the 16 pixels on the lanes of a row group
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (cl == 0) {
+          const int col = 64 * wn + 16 * j + 4 * g + e;
+          red[(wm * BN + col) * 2] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.Cd) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += red[(w * BN + tid) * 2];
+          s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
+        atomic_add_f64(st + n, (double)s1);
+        atomic_add_f64(st + p.Cd + n, (double)s2);
+      }
+    }
+  }
+}
+
+}  // namespace v5
+
+bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
+  static const bool off = getenv("DY_NO_CONV_V5") != nullptr;
+  if (off || d->dtype != DY_BF16) return false;
+  if (!(d->Cs % 32 == 0 && d->KH * d->KW <= 25)) return false;
+  if (mode == 1 && d->stride != 1) return false;
+  if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0) return false;
+  const long M = (long)d->N * d->Hd * d->Wd;
+  const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
+  const long w_row = d->KHf > 0 ? (long)d->KHf * d->KWf * d->Cs : (long)d->KH * d->KW * d->Cs;
+  const long w_bytes = (long)d->Cd * w_row * 2;
+  if (!(src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL && M < (1L << 31))) return false;
+  const long tiles_m = (M + 255) / 256;
+  const long tn = (d->Cd + 127) / 128;
+  if (d->Cd >= 96 && tn * 128 * 4 <= (long)d->Cd * 5 && tiles_m * tn >= 256) return true;
+  return d->Cd >= 48 && d->Cd <= 64 && tiles_m >= 256;          // 64-wide tiles for the 64-channel layers
+}
+
+int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
+  v5::P p;
+  p.src = (const char*)d->src; p.w = (const char*)d->w; p.dst = (char*)d->dst;
+  p.src_ld = d->src_ld; p.dst_ld = d->dst_ld;
+  p.src_bytes = (unsigned)((((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2);
+  p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd;
+  p.KH = d->KH; p.KW = d->KW;
+  if (mode == 0) {
+    p.stride = d->stride; p.dh0 = -d->pad; p.dhs = d->dil; p.dw0 = -d->pad; p.dws = d->dil;
+  } else {               // stride-1 data gradient: dx[h] += dz[h + pad - kh*dil] * w[kh]
+    p.stride = 1; p.dh0 = d->pad; p.dhs = -d->dil; p.dw0 = d->pad; p.dws = -d->dil;
+  }
+  if (d->KHf > 0) {
+    p.kh0 = d->kh0; p.khs = d->kh_step; p.kw0 = d->kw0; p.kws = d->kw_step; p.KWf = d->KWf;
+    p.w_row = (long)d->KHf * d->KWf * d->Cs;
+  } else {
+    p.kh0 = 0; p.khs = 1; p.kw0 = 0; p.kws = 1; p.KWf = d->KW;
+    p.w_row = (long)d->KH * d->KW * d->Cs;
+  }
+  p.w_bytes = (unsigned)((long)d->Cd * p.w_row * 2);
+  p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
+  p.M = (long)d->N * d->Hd * d->Wd;
+  p.nk = d->KH * d->KW * d->Cs / v5::BK;
+  p.dst_row = d->dst_row_stride;
+  p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
+  const int bn = d->Cd <= 64 ? 64 : 128;
+  p.tiles_n = dy_cdiv(d->Cd, bn);
+  p.nblk = dy_cdiv(p.M, v5::BM) * p.tiles_n;
+  constexpr int RING128 = v5::NSTAGE * (v5::A_BYTES + 128 * 64), EPI128 = dy_epi::row_image_bytes<v5::BM, 128>();
+  constexpr int RING64 = v5::NSTAGE * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
+  constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
+  static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024, "two blocks per CU");
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
+    if (e != hipSuccess) {
+      dy_set_error("conv_v5: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 3;
+    }
+    configured = true;
+  }
+  if (bn == 128) {
+    dy_note_kernel("v5::conv_kernel<128>");
+    v5::conv_kernel<128><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
+  } else {
+    dy_note_kernel("v5::conv_kernel<64>");
+    v5::conv_kernel<64><<<p.nblk, 256, SH64, (hipStream_t)stream>>>(p);
+  }
+  DY_LAUNCH_CHECK();
+  return 0;
+}

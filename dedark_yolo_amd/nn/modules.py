@@ -546,7 +546,10 @@ class Detect(DyModule):
         """fn(tapes[i], i, args[i]) for every pyramid level.  The levels are independent chains of small kernels (three convs
         + BatchNorm each way), so when the trainer enabled branch streams the coarser levels run on side streams next to
         level 0 on the compute stream: fork before, join after (everything later on the compute stream is ordered behind
-        them, which also covers the allocator's reuse of the operands)."""
+        them).  The operand of a side level was allocated on the compute stream: it is marked as used by the side stream
+        (record_stream), because the host drops its last reference (tape pop in the backward pass) while the side stream's
+        kernels that read it are still queued -- without the mark the caching allocator hands the block to the next
+        compute-stream allocation (level 0's weight gradient) at once and that kernel overwrites it first."""
         n = len(args)
         side = ops.branch_streams(n - 1, args[0].device) if (self.training and tapes[0] is not None) else None
         out = [None] * n
@@ -558,6 +561,7 @@ class Detect(DyModule):
         for i in range(1, n):                       # issue the side levels first: they run while level 0 is being issued
             s = side[i - 1]
             call("dy_stream_fork", main_raw, s.cuda_stream)
+            args[i].record_stream(s)
             with torch.cuda.stream(s):
                 out[i] = fn(tapes[i], i, args[i])
         out[0] = fn(tapes[0], 0, args[0])

@@ -113,7 +113,7 @@ class GraphPlan:
             ins = [x if sidx < 0 else outs[sidx] for sidx in src]
             outs[i] = call_layer(m, ins if as_list else ins[0])
             for sidx in self.dead_after[i]:
-                outs[sidx] = None                 # last consumer done: the buffer goes back to the allocator now
+                outs[sidx] = None                     # last consumer done: the buffer goes back to the allocator now
         return outs[-1]
 
 

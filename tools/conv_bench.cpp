@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
         {"n 1x1 256->128 @20", B, 256, 128, 20, 20, 1, 1, 0},
     };
   }
+  const int warm = getenv("CB_WARM") ? atoi(getenv("CB_WARM")) : 40;
   const char* only = getenv("CB_ONLY");          // substring filter on the shape name
   const bool check = getenv("CB_CHECK") != nullptr;   // sampled CPU check of fwd / dgrad / wgrad outputs
   hipStream_t st;
@@ -86,7 +87,7 @@ int main(int argc, char** argv) {
                                   scratch, scratch_elems, gw, DY_BF16, st);
         if (rc) { printf("call failed: %s\n", dy_last_error()); exit(1); }
       };
-      for (int i = 0; i < 3; ++i) run();
+      for (int i = 0; i < warm; ++i) run();          // the clock needs ~10 ms of load to settle: 3 launches read 10-15 % slow
       CK(hipStreamSynchronize(st));
       CK(hipEventRecord(e0, st));
       for (int i = 0; i < iters; ++i) run();
@@ -173,7 +174,7 @@ int main(int argc, char** argv) {
            flops / 1e9, ms[0] * 1e3, flops / ms[0] / 1e9, flops / ms[0] / 1e9 / 25.0, ms[1] * 1e3, flops / ms[1] / 1e9, ms[2] * 1e3,
            flops / ms[2] / 1e9);
     fflush(stdout);
-    hipFree(dx); hipFree(dw); hipFree(dwt); hipFree(dy); hipFree(dz); hipFree(gw); hipFree(stats);
+    CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dwt)); CK(hipFree(dy)); CK(hipFree(dz)); CK(hipFree(gw)); CK(hipFree(stats));
   }
   return 0;
 }

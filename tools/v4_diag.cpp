@@ -57,10 +57,42 @@ int main(int argc, char** argv) {
   run<2>("no MFMA", f, flops, st, it);
   run<8>("no stagger (groups in lockstep)", f, flops, st, it);
   run<64>("no epilogue stores", f, flops, st, it);
+  run<128>("no s_setprio around the MFMA clusters", f, flops, st, it);
+  run<128 | 256>("priority to the loading wave", f, flops, st, it);
+  run<0>("shipped kernel (again)", f, flops, st, it);
+  run<128>("no s_setprio (again)", f, flops, st, it);
+  if (Cc >= 192) {
+    run<1024>("DMA issued inside the MFMA clusters", f, flops, st, it);
+    run<0>("shipped kernel (again)", f, flops, st, it);
+    run<1024>("DMA inside the MFMA clusters (again)", f, flops, st, it);
+  }
   run<1 | 4>("MFMA + barriers only", f, flops, st, it);
   run<1 | 2>("LDS reads + barriers only", f, flops, st, it);
   run<2 | 4>("DMA + barriers only", f, flops, st, it);
   run<1 | 2 | 4>("barriers + scalar bookkeeping only", f, flops, st, it);
   run<0>("shipped kernel (again)", f, flops, st, it);
+  if (Cc >= 192) {        // phase stamps (256 x 256 kernel): cycles per K-step of [reads + DMA issue + barrier | MFMA cluster | second barrier]
+    unsigned long long* dbg;
+    CK(hipMalloc(&dbg, 24 * 8));
+    CK(hipMemset(dbg, 0, 24 * 8));
+    f.stats = (double*)dbg;
+    run<512>("stamped build (not a timing)", f, flops, st, 1);
+    unsigned long long h[24];
+    CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    const double nks = (double)(k * k * Cc / 64) * 4.0;     // 3 warm-up launches + 1 timed one accumulate into the same sums... per launch reset below
+    (void)nks;
+    for (int w = 0; w < 2; ++w) {
+      printf("  group %d (wave %d) cycles per K-step and phase  [load part + wait | MFMA cluster | second barrier]\n", w, 4 * w);
+      double tot = 0;
+      for (int ph = 0; ph < 4; ++ph) {
+        const double a = h[12 * w + 3 * ph] / (double)(k * k * Cc / 64), b = h[12 * w + 3 * ph + 1] / (double)(k * k * Cc / 64),
+                     c = h[12 * w + 3 * ph + 2] / (double)(k * k * Cc / 64);
+        printf("    P%d  %7.0f | %7.0f | %7.0f\n", ph + 1, a, b, c);
+        tot += a + b + c;
+      }
+      printf("    sum %7.0f cycles per K-step (1024 cycles of MFMA per wave; the stamps themselves cost ~40 each)\n", tot);
+    }
+    f.stats = nullptr;
+  }
   return 0;
 }
