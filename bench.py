@@ -239,11 +239,20 @@ def pmc_traffic(tag, kernel):
             continue
         with open(path) as fh:
             ks = json.load(fh).get("kernels", {})
-        base = kernel.split("+")[0]
-        hit = [v for k, v in ks.items() if k == base or k.startswith(base + "<") or k.startswith(base + "(")]
+        base, _, tail = kernel.partition("+")
+        match = lambda k, b: k == b or k.startswith(b + "<") or k.startswith(b + "(")
+        hit = [v for k, v in ks.items() if match(k, base)]
         if hit:
             tot = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in hit)
             n = sum(v["launches"] for v in hit)
+            if tail:        # "ns::main_kernel+reduce_kernel": the split reduction of the same namespace belongs to the launch
+                ns = base.split("::")[0] + "::" if "::" in base else ""
+                red = [v for k, v in ks.items() if match(k, ns + tail)]
+                share = 1.0
+                if ns:      # the reduce kernel is shared by all instantiations of the namespace: prorate by launches
+                    allmain = sum(v["launches"] for k, v in ks.items() if k.startswith(ns) and not match(k, ns + tail))
+                    share = n / max(allmain, 1)
+                tot += share * sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in red)
             return round(tot / max(n, 1)), "profiles/" + f
     return None, None
 
@@ -308,7 +317,7 @@ def main():
         raise SystemExit(f"non-finite loss {final_loss}")
 
     wl, tag = workload_tag(args)
-    out = dict(metric="training img/s at 640x640", value=round(args.batch * world * args.steps / el, 2), unit="img/s",
+    out = dict(metric=f"training img/s at {args.imgsz}x{args.imgsz}", value=round(args.batch * world * args.steps / el, 2), unit="img/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1000 * el / args.steps, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"{wl}: {args.model}, {args.imgsz}x{args.imgsz}, "

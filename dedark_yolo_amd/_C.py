@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdedark_yolo.so")
 
-DY_F32, DY_BF16 = 0, 1
+DY_F32, DY_BF16, DY_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
 STATS_REPLICAS = 64          # DY_STATS_REPLICAS of include/dedark_yolo.h
 BN_BWD_REPLICAS = 8          # DY_BN_BWD_REPLICAS
@@ -75,6 +75,8 @@ _SIGS = {
     "dy_loss_decode": [C.POINTER(DetMaps), vp, vp],
     "dy_tal_assign": [C.POINTER(DetMaps), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "dy_tal_assign_decoded": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "dy_bbox_ciou": [vp, vp, i64, vp, vp, vp],
+    "dy_dfl_loss": [vp, vp, i64, vp, vp, vp],
     "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],
     "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],
     "dy_loss_bwd": [C.POINTER(DetMaps), vp * 3, i64 * 3, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp],
@@ -85,6 +87,9 @@ _SIGS = {
     "dy_preprocess_batch": [vp, vp, vp, f32, i32, i32, vp, i64, vp],
     "dy_sumsq": [vp, i64, vp, vp],
     "dy_sgd_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],
+    "dy_sgd_step_scaled": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, vp, i64, vp],
+    "dy_adamw_step_scaled": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, vp, i64, vp],
+    "dy_loss_scale_update": [vp, vp, f32, f32, i32, vp],
     "dy_adamw_step": [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i32, f32, vp, f32, f32, i64, vp],
     "dy_ema_lerp": [vp, vp, f32, i64, vp],
     "dy_grad_accumulate": [vp, vp, i64, vp],

@@ -379,6 +379,7 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
 #define FWD(T_, U_) bn_act_fwd_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
                                                                     (T_*)y, y_ld, pixels, C, g.cgb, g.rows)
   if (dtype == DY_F32) { if (big) FWD(float, 4); else FWD(float, 2); }
+  else if ((dtype) == DY_F16) { if (big) FWD(f16_t, 4); else FWD(f16_t, 2); }
   else { if (big) FWD(bf16_t, 4); else FWD(bf16_t, 2); }
 #undef FWD
   DY_LAUNCH_CHECK();
@@ -400,6 +401,9 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   if (dtype == DY_F32)
     bn_act_bwd_reduce_kernel<float, 2><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
                                                                 invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+  else if ((dtype) == DY_F16)
+    bn_act_bwd_reduce_kernel<f16_t, 2><<<g.grid, NT, shm, st>>>((const f16_t*)dy, dy_ld, (const f16_t*)z, z_ld, scale, shift,
+                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
   else
     bn_act_bwd_reduce_kernel<bf16_t, 2><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
                                                                  mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
@@ -426,6 +430,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
                                                                             gamma, act, has_bn, sums, (T_*)dz, dz_ld, dgamma, dbeta, pixels, \
                                                                             pixels > 0 ? pixels : 1, C, g.cgb, g.rows)
   if (dtype == DY_F32) { if (big) APPLY(float, 1); else APPLY(float, 2); }
+  else if ((dtype) == DY_F16) { if (big) APPLY(f16_t, 1); else APPLY(f16_t, 2); }
   else { if (big) APPLY(bf16_t, 1); else APPLY(bf16_t, 2); }
 #undef APPLY
   DY_LAUNCH_CHECK();

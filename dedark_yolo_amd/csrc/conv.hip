@@ -31,7 +31,7 @@ int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
 bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, long x_ld, long dz_ld);
 int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream);
+                       long scratch_elems, float* g_oihw, int dtype, void* stream);
 // whole-input windows = fully connected layers (dense.hip)
 bool dy_dense_fwd_eligible(const dy_conv_desc* d);
 int dy_dense_fwd_launch(const dy_conv_desc* d, void* stream);
@@ -45,11 +45,11 @@ bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
                           long dz_ld, long scratch_elems);
 int dy_wgrad_v4_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream);
+                       long scratch_elems, float* g_oihw, int dtype, void* stream);
 bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
                           long x_ld, long dz_ld, long scratch_elems);
 int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
-                       int Cin, float* scratch, long scratch_elems, float* g_oihw, void* stream);
+                       int Cin, float* scratch, long scratch_elems, float* g_oihw, int dtype, void* stream);
 // direct stem kernels (conv_small.hip)
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
 int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream);
@@ -120,9 +120,7 @@ __device__ inline void mma_step(const char* As, const char* Bs, int a_row0, int 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (sizeof(T) == 2) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
-                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]),
-                                                              acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<T>(af[i], bfr[j], acc[i][j]);
         } else {
           // lane half h holds k = kk*8 + 4h + q; A and B use the same k permutation, so the sum is exact
           const f32x4 fa = __builtin_bit_cast(f32x4, af[i]);
@@ -299,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
     static_assert(dy_epi::image_bytes<BM, BN>() <= (BM + BN) * ROWB, "epilogue image must fit the staging buffers");
     if (!(p.ablate & 4))
       dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act,
-                                                 p.accumulate, reinterpret_cast<bf16_t*>(dst),
+                                                 p.accumulate, dst,
                                                  [&](long m) { return dst_offset(p, m); }, csum, csq);
   } else {
     int nn[TN];
@@ -554,6 +552,8 @@ template <> struct Transposer<bf16_t, 8> {
   }
 };
 
+template <> struct Transposer<f16_t, 8> : Transposer<bf16_t, 8> {};      // 16-bit payloads: the same shuffle
+
 // The small tiles are latency-bound (one global-load round trip per 64-pixel step): cap them at 128 VGPRs so that four blocks
 // share a CU instead of three (they compile to 132 without the bound).
 template <typename T, int BM, int BN, int WM, int WN>
@@ -792,6 +792,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const dy_pack_item* __r
     }
     const float v = (ci < it.Cin && co < it.Cout) ? it.w[(((long)co * it.Cin + ci) * it.KH + kh) * it.KW + kw] : 0.f;
     if (it.dtype == DY_F32) ((float*)it.packed)[i] = v;
+    else if (it.dtype == DY_F16) ((f16_t*)it.packed)[i] = (f16_t)v;
     else ((bf16_t*)it.packed)[i] = f32_to_bf16(v);
   }
 }
@@ -913,7 +914,7 @@ int launch_thin(const dy_conv_desc* d, int mode, hipStream_t st, const dy_conv_d
 
 int check_conv(const dy_conv_desc* d, const char* who) {
   DY_CHECK(d && d->src && d->w && (d->dst || d->dst_planar), "%s: null pointer", who);
-  DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16, "%s: bad dtype %d", who, d->dtype);
+  DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16 || d->dtype == DY_F16, "%s: bad dtype %d", who, d->dtype);
   const int ve = d->dtype == DY_F32 ? 4 : 8, es = d->dtype == DY_F32 ? 4 : 2;
   DY_CHECK(d->Cs > 0 && d->Cs % ve == 0, "%s: Cs=%d must be a positive multiple of %d", who, d->Cs, ve);
   DY_CHECK(d->src_ld >= d->Cs && (d->src_ld * es) % 16 == 0, "%s: src_ld=%ld not 16-byte aligned", who, (long)d->src_ld);
@@ -939,7 +940,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 0, stream);
   hipStream_t st = (hipStream_t)stream;
   if (thin_eligible(d, 0)) return launch_thin(d, 0, st);
-  return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : launch_conv<bf16_t, 0>(d, st);
+  return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : (d->dtype == DY_F16 ? launch_conv<f16_t, 0>(d, st) : launch_conv<bf16_t, 0>(d, st));
 }
 
 extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
@@ -1012,7 +1013,8 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
           if (thin) return launch_thin(&r[0], 0, (hipStream_t)stream, r, nc);
           if (class_tiles <= 256)
             return d->dtype == DY_F32 ? launch_conv<float, 0>(&r[0], (hipStream_t)stream, r, nc)
-                                      : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc);
+                 : (d->dtype == DY_F16 ? launch_conv<f16_t, 0>(&r[0], (hipStream_t)stream, r, nc)
+                                       : launch_conv<bf16_t, 0>(&r[0], (hipStream_t)stream, r, nc));
         }
       }
       for (int i = nc - 1; i >= 0; --i) {    // heaviest class (most taps) first
@@ -1021,7 +1023,8 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
         if (dy_conv_v4_eligible(q, 0)) e = dy_conv_v4_launch(q, 0, stream);
         else if (dy_conv_v5_eligible(q, 0)) e = dy_conv_v5_launch(q, 0, stream);
         else if (dy_conv_v2_eligible(q)) e = dy_conv_v2_launch(q, 0, stream);
-        else e = q->dtype == DY_F32 ? launch_conv<float, 0>(q, (hipStream_t)stream) : launch_conv<bf16_t, 0>(q, (hipStream_t)stream);
+        else e = q->dtype == DY_F32 ? launch_conv<float, 0>(q, (hipStream_t)stream)
+                                    : (q->dtype == DY_F16 ? launch_conv<f16_t, 0>(q, (hipStream_t)stream) : launch_conv<bf16_t, 0>(q, (hipStream_t)stream));
         if (e) return e;
       }
       return 0;
@@ -1033,7 +1036,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;
   if (thin_eligible(d, 1)) return launch_thin(d, 1, st);
-  return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : launch_conv<bf16_t, 1>(d, st);
+  return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : (d->dtype == DY_F16 ? launch_conv<f16_t, 1>(d, st) : launch_conv<bf16_t, 1>(d, st));
 }
 
 namespace {
@@ -1089,7 +1092,7 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
                                int Ho, int Wo, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin,
                                float* scratch, int64_t scratch_elems, float* g_oihw, int dtype, void* stream) {
   DY_CHECK(x && dz && scratch && g_oihw, "dy_conv2d_wgrad: null pointer");
-  DY_CHECK(dtype == DY_F32 || dtype == DY_BF16, "dy_conv2d_wgrad: bad dtype");
+  DY_CHECK(dtype == DY_F32 || dtype == DY_BF16 || dtype == DY_F16, "dy_conv2d_wgrad: bad dtype");
   const int ve = dtype == DY_F32 ? 4 : 8, es = dtype == DY_F32 ? 4 : 2;
   DY_CHECK(Cin_pad % ve == 0 && Cout_pad % ve == 0, "dy_conv2d_wgrad: Cin=%d / Cout=%d must be multiples of %d", Cin_pad, Cout_pad, ve);
   DY_CHECK(Cout > 0 && Cout <= Cout_pad && Cin > 0 && Cin <= Cin_pad, "dy_conv2d_wgrad: bad real channel counts");
@@ -1100,13 +1103,13 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   if (dy_dense_wgrad_eligible(Hi, Wi, Ho, Wo, KH, KW, pad, dil))
     return dy_dense_wgrad_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout, Cin, g_oihw, dtype, stream);
   if (dy_wgrad_v3_eligible(dtype, Cin_pad, Cout_pad, KH, KW, stride, pad, dil, N, Hi, Wi, x_ld, dz_ld, scratch_elems))
-    return dy_wgrad_v3_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout_pad, Cout, Cin, scratch, scratch_elems, g_oihw, stream);
+    return dy_wgrad_v3_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Cout_pad, Cout, Cin, scratch, scratch_elems, g_oihw, dtype, stream);
   if (dy_wgrad_v4_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, N, Hi, Wi, Ho, Wo, x_ld, dz_ld, scratch_elems))
     return dy_wgrad_v4_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
-                              scratch_elems, g_oihw, stream);
+                              scratch_elems, g_oihw, dtype, stream);
   if (dy_wgrad_v2_eligible(dtype, Cin_pad, Cout_pad, KH, KW, (long)N * Ho * Wo, x_ld, dz_ld))
     return dy_wgrad_v2_launch(x, x_ld, N, Hi, Wi, Cin_pad, dz, dz_ld, Ho, Wo, Cout_pad, KH, KW, stride, pad, dil, Cout, Cin, scratch,
-                              scratch_elems, g_oihw, stream);
+                              scratch_elems, g_oihw, dtype, stream);
   WgP p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
   p.dz = (const char*)dz; p.dz_ld = dz_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout_pad;
@@ -1116,7 +1119,8 @@ extern "C" int dy_conv2d_wgrad(const void* x, int64_t x_ld, int N, int Hi, int W
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == DY_F32 ? launch_wgrad<float>(p, scratch, scratch_elems, g_oihw, Cout, Cin, st)
-                         : launch_wgrad<bf16_t>(p, scratch, scratch_elems, g_oihw, Cout, Cin, st);
+                         : (dtype == DY_F16 ? launch_wgrad<f16_t>(p, scratch, scratch_elems, g_oihw, Cout, Cin, st)
+                                            : launch_wgrad<bf16_t>(p, scratch, scratch_elems, g_oihw, Cout, Cin, st));
 }
 
 extern "C" int dy_pack_weight(const float* w, void* packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int KH, int KW,
@@ -1127,6 +1131,7 @@ extern "C" int dy_pack_weight(const float* w, void* packed, int Cout, int Cout_p
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DY_F32) pack_weight_kernel<float><<<blocks, 256, 0, st>>>(w, (float*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
+  else if (dtype == DY_F16) pack_weight_kernel<f16_t><<<blocks, 256, 0, st>>>(w, (f16_t*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
   else pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, (bf16_t*)packed, Cout, Cout_pad, Cin, Cin_pad, KH, KW, transposed);
   DY_LAUNCH_CHECK();
   return 0;

@@ -1,4 +1,4 @@
-// Shared epilogue of the bf16 conv kernels (conv.hip, conv_v2.hip, conv_v3.hip): f32 accumulators -> affine + activation ->
+// Shared epilogue of the 16-bit (bf16 / f16) conv kernels (conv.hip, conv_v2.hip, conv_v3.hip): f32 accumulators -> affine + activation ->
 // bf16 tile in HBM with 16-byte stores, plus the per-channel (sum, sum of squares) of the RAW accumulators for BatchNorm.
 //
 // The 32x32 MFMA leaves lane (col = lane&31, half hh = lane>>5) with rows (r&3) + 8*(r>>2) + 4*hh of ONE column: four
@@ -22,12 +22,13 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 template <int BM, int BN>
 constexpr int image_bytes() { return BN * pitch<BM>(); }
 
-__device__ inline uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+template <typename T16 = bf16_t>
+__device__ inline uint32_t pack2(float a, float b) { return (uint32_t)cvt16<T16>(a) | ((uint32_t)cvt16<T16>(b) << 16); }
 
 // Store phase: the transposed image [BN cols][BM rows] (pitch<BM>() bytes per column) -> HBM.  Unit = 16 pixels x 32 channels
 // per wave instruction; NW waves share the units.  The caller has synchronised the block after writing the image.
-template <int BM, int BN, int NW, typename OffFn>
-__device__ inline void store_image(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, bf16_t* dst,
+template <int BM, int BN, int NW, typename T16, typename OffFn>
+__device__ inline void store_image(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, T16* dst,
                                    OffFn off) {
   constexpr int PT = pitch<BM>();
   constexpr int UP = BM / 16, UC = BN / 32;
@@ -50,21 +51,24 @@ __device__ inline void store_image(const char* smem, int lane, int wave, long m0
       v[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
       v[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
       v[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-      bf16_t* o = dst + off(m) + n;
+      T16* o = dst + off(m) + n;
       if (n + 8 <= Cd) {
         if (accumulate) {
           float x[8], y[8];
-          ldvec<bf16_t>(o, x);
-          ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+          ldvec<T16>(o, x);
+          ldvec<T16>(reinterpret_cast<const T16*>(&v), y);
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] += y[e];
-          stvec<bf16_t>(o, x);
+          stvec<T16>(o, x);
         } else {
           *reinterpret_cast<u32x4*>(o) = v;
         }
       } else {                                     // ragged channel tail (never happens for padded views)
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-        for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+        const T16* e = reinterpret_cast<const T16*>(&v);
+        for (int q = 0; q < 8 && n + q < Cd; ++q) {
+          if (accumulate) DT<T16>::st(o + q, DT<T16>::ld(o + q) + DT<T16>::ld(e + q));
+          else o[q] = e[q];
+        }
       }
     }
   }
@@ -82,8 +86,8 @@ constexpr int row_pitch() { return BN * 2 + 8; }
 template <int BM, int BN>
 constexpr int row_image_bytes() { return BM * row_pitch<BN>(); }
 
-template <int BM, int BN, int NW, typename OffFn>
-__device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, bf16_t* dst, OffFn off) {
+template <int BM, int BN, int NW, typename T16, typename OffFn>
+__device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, T16* dst, OffFn off) {
   constexpr int PT = row_pitch<BN>();
   constexpr int LPP = BN >= 128 ? 16 : BN / 8;      // lanes (16-byte chunks) per pixel and instruction: 16 (256 B) or 8 (BN = 64: 128 B)
   constexpr int PPI = 64 / LPP;                     // pixels per wave instruction
@@ -102,21 +106,24 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
       const int n = n0 + c;
       if (m < M && n < Cd) {
         u32x4 v = {lo.x, lo.y, hi.x, hi.y};
-        bf16_t* o = dst + off(m) + n;
+        T16* o = dst + off(m) + n;
         if (n + 8 <= Cd) {
           if (accumulate) {
             float x[8], y[8];
-            ldvec<bf16_t>(o, x);
-            ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(&v), y);
+            ldvec<T16>(o, x);
+            ldvec<T16>(reinterpret_cast<const T16*>(&v), y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += y[e];
-            stvec<bf16_t>(o, x);
+            stvec<T16>(o, x);
           } else {
             *reinterpret_cast<u32x4*>(o) = v;
           }
         } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int q = 0; q < 8 && n + q < Cd; ++q) o[q] = accumulate ? f32_to_bf16(bf16_to_f32(o[q]) + bf16_to_f32(e[q])) : e[q];
+          const T16* e = reinterpret_cast<const T16*>(&v);
+          for (int q = 0; q < 8 && n + q < Cd; ++q) {
+            if (accumulate) DT<T16>::st(o + q, DT<T16>::ld(o + q) + DT<T16>::ld(e + q));
+            else o[q] = e[q];
+          }
         }
       }
     }
@@ -124,9 +131,9 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
 }
 
 // Block tile BM x BN on WM x WN waves (wave tile 32*TM x 32*TN).  `off(m)` = element offset of output pixel m.
-template <int BM, int BN, int WM, int WN, int TM, int TN, typename OffFn>
+template <int BM, int BN, int WM, int WN, int TM, int TN, typename T16, typename OffFn>
 __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int wn, int lane, int wave, long m0, int n0, long M, int Cd,
-                                  const float* scale, const float* shift, int act, int accumulate, bf16_t* dst, OffFn off,
+                                  const float* scale, const float* shift, int act, int accumulate, T16* dst, OffFn off,
                                   float (&csum)[TN], float (&csq)[TN]) {
   constexpr int PT = pitch<BM>();
   static_assert(BM / WM == 32 * TM && BN / WN == 32 * TN, "wave tiling");
@@ -160,7 +167,7 @@ __device__ inline void store_tile(char* smem, f32x16 (&acc)[TM][TN], int wm, int
           else if (act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
           v[e] = u;
         }
-        uint2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+        uint2 w = {pack2<T16>(v[0], v[1]), pack2<T16>(v[2], v[3])};
         *reinterpret_cast<uint2*>(smem + col * PT + (row0 + 8 * rq) * 2) = w;
       }
     }

@@ -56,6 +56,7 @@ struct P {
   int kh0, khs, kw0, kws, KWf;    // window tap -> weight tap mapping (tap subsets of a parity-split data gradient)
   long w_row;                     // elements per output-channel row of the weight pack
   int ncls;                       // > 1: parity classes of a stride-2 data gradient in one launch
+  int f16;                        // payload is IEEE half instead of bf16 (host side: selects the instantiation)
   DyParityCls cls[4];
 };
 
@@ -77,7 +78,7 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 // SMALLC: Cs is not a multiple of 64 (the n-scale layers, 8..48 channels): a 64-wide K-step then spans several taps, so every
 // lane derives (tap, channel) of ITS 16-byte chunk; K = KH*KW*Cs is padded to the step with zero-page loads.
 // BM x BN block tile on (BM/64) x 2 waves (wave tile 64 x BN/2); NSTAGE-deep LDS ring.
-template <int BM, int BN, int MODE, bool SMALLC, int NSTAGE>
+template <int BM, int BN, int MODE, bool SMALLC, int NSTAGE, typename T = bf16_t>
 __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
   P p = pk;
   constexpr int WN = 2, WM = BM / 64, NW = WM * WN, NT = 64 * NW;
@@ -255,9 +256,7 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
-                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[j]),
-                                                              acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
     }
   }
 
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
   float csum[TN], csq[TN];
   if (!(p.ablate & 4))
     dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
-                                   reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
+                                   reinterpret_cast<T*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
   stamp(p.ablate, 6);
   stamp(p.ablate, 7);
   if (p.stats) {
@@ -302,14 +301,14 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
   }
 }
 
-template <int BN, int MODE, bool SMALLC, int NSTAGE = 3, int BM = 256>
-int launch(P& p, hipStream_t st) {
+template <int BN, int MODE, bool SMALLC, int NSTAGE, int BM, typename T>
+int launch_t(P& p, hipStream_t st) {
   constexpr int RING = NSTAGE * (BM + BN) * ROW, EPI = dy_epi::image_bytes<BM, BN>();
   constexpr int SHMEM = RING > EPI ? RING : EPI;            // the epilogue image reuses the ring
   static_assert(SHMEM <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BM, BN, MODE, SMALLC, NSTAGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BM, BN, MODE, SMALLC, NSTAGE, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) {
       dy_set_error("conv_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -330,9 +329,14 @@ int launch(P& p, hipStream_t st) {
   static char name[64];
   if (!name[0]) snprintf(name, sizeof(name), "v2::conv_kernel<%d, %d, %d, %s, %d>", BM, BN, MODE, SMALLC ? "true" : "false", NSTAGE);
   dy_note_kernel(name);
-  conv_kernel<BM, BN, MODE, SMALLC, NSTAGE><<<p.nblk, BM * 2, SHMEM, st>>>(p);
+  conv_kernel<BM, BN, MODE, SMALLC, NSTAGE, T><<<p.nblk, BM * 2, SHMEM, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BN, int MODE, bool SMALLC, int NSTAGE = 3, int BM = 256>
+int launch(P& p, hipStream_t st) {
+  return p.f16 ? launch_t<BN, MODE, SMALLC, NSTAGE, BM, f16_t>(p, st) : launch_t<BN, MODE, SMALLC, NSTAGE, BM, bf16_t>(p, st);
 }
 
 }  // namespace v2
@@ -356,7 +360,7 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d) {
   static const bool off = getenv("DY_NO_CONV_V2") != nullptr;
   if (off) return false;
   const long M = (long)d->N * d->Hd * d->Wd;
-  if (!(d->dtype == DY_BF16 && M >= 2048 && (d->src_ld * 2) % 16 == 0)) return false;
+  if (!((d->dtype == DY_BF16 || d->dtype == DY_F16) && M >= 2048 && (d->src_ld * 2) % 16 == 0)) return false;
   if (d->Cs % 64 == 0) return d->Cd >= 64;
   // narrow SOURCE channels (per-lane tap decode, SMALLC).  Measured on the n-scale layers: a win only when the destination is
   // at least one 64-wide tile (96->64 1x1: 50 -> 40 us, 32->64 3x3 s2: 61 -> 54 us); with Cd <= 32 the 256x64 tile is 50-75 %
@@ -377,6 +381,7 @@ int dy_conv_v2_launch_classes(const dy_conv_desc* classes, int ncls, void* strea
 
 static int v2_launch_impl(const dy_conv_desc* d, int mode, const dy_conv_desc* classes, int ncls, void* stream) {
   v2::P p;
+  p.f16 = d->dtype == DY_F16;
   p.ncls = 0;
   if (ncls > 1) {
     DY_CHECK(ncls <= 4, "conv_v2: at most 4 classes");

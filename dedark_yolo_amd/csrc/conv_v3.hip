@@ -55,6 +55,7 @@ struct P {
   int a_bytes;          // bytes of one band buffer (L rounded up to 64 rows)
   int nslices;          // ceil(L / 64)
   int ablate;           // DY_ABLATE diagnostics: 1 no band prefetch, 64 no weight-tile loads in the loop, 2 no MFMA, 32 stamps
+  int f16;              // payload is IEEE half instead of bf16 (host side: selects the instantiation)
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -63,7 +64,7 @@ __device__ inline int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, typename T = bf16_t>
 __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
   constexpr int WN = 2, WM = 4;
   constexpr int TM = BM / WM / 32;          // 2
@@ -239,9 +240,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[kk][i]),
-                                                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[kk][j]),
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_32x32x16<T>(af[kk][i], bf[kk][j], acc[i][j]);
       }
       __builtin_amdgcn_s_barrier();
     }
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
   float csum[TN], csq[TN];
   if (!(p.ablate & 4))
     dy_epi::store_tile<BM, BN, 4, 2, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
-                                   reinterpret_cast<bf16_t*>(p.dst), [&](long m) { return m * p.dst_ld; }, csum, csq);
+                                   reinterpret_cast<T*>(p.dst), [&](long m) { return m * p.dst_ld; }, csum, csq);
   stamp(p.ablate, 6);
   stamp(p.ablate, 7);
   if (p.stats) {
@@ -299,12 +298,12 @@ int shmem_bytes(const P& p) {
   return ring > epi ? ring : epi;
 }
 
-template <int BN, int MODE>
-int launch(P& p, hipStream_t st) {
+template <int BN, int MODE, typename T>
+int launch_t(P& p, hipStream_t st) {
   const int shm = shmem_bytes<BN>(p);
   static int configured = 0;
   if (shm > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BN, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BN, MODE, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     if (e != hipSuccess) {
       dy_set_error("conv_v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -315,9 +314,14 @@ int launch(P& p, hipStream_t st) {
   p.tiles_n = dy_cdiv(p.Cd, BN);
   p.nblk = dy_cdiv(p.M, BM) * p.tiles_n;
   dy_note_kernel(BN == 128 ? (MODE ? "v3::conv3x3_kernel<128, 1>" : "v3::conv3x3_kernel<128, 0>") : (MODE ? "v3::conv3x3_kernel<64, 1>" : "v3::conv3x3_kernel<64, 0>"));
-  conv3x3_kernel<BN, MODE><<<p.nblk, NT, shm, st>>>(p);
+  conv3x3_kernel<BN, MODE, T><<<p.nblk, NT, shm, st>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BN, int MODE>
+int launch(P& p, hipStream_t st) {
+  return p.f16 ? launch_t<BN, MODE, f16_t>(p, st) : launch_t<BN, MODE, bf16_t>(p, st);
 }
 
 }  // namespace v3
@@ -327,6 +331,7 @@ static void v3_fill(const dy_conv_desc* d, v3::P& p) {
   p.w = (const char*)d->w; p.dst = (char*)d->dst; p.dst_ld = d->dst_ld; p.Cd = d->Cd;
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hs * d->Ws;
+  p.f16 = d->dtype == DY_F16;
   p.Ktot = 9 * d->Cs;
   p.L = v3::BM + 2 * (d->Ws + 1);
   p.nslices = (p.L + 64) / 64;      // >= one spare row past L: the always-zero row used for out-of-image taps
@@ -345,7 +350,7 @@ bool dy_conv_prefers_256(const dy_conv_desc* d);      // conv_v2.hip
 bool dy_conv_v3_eligible(const dy_conv_desc* d) {
   static const bool off = getenv("DY_NO_CONV_V3") != nullptr;
   if (off) return false;
-  if (!(d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
+  if (!((d->dtype == DY_BF16 || d->dtype == DY_F16) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
   if (d->KHf != 0 || d->dst_row_stride != 0) return false;    // tap subsets / strided destinations: generic kernels only
   // Cd <= 64 goes to conv_v2's 256x64 two-blocks-per-CU configuration (20 % faster than the 64-wide band variant) and
   // Cd >= 256 with enough tiles to its 256x256 tile (256->256 at 40x40: 190 us against 221 us here)

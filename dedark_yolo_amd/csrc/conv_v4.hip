@@ -79,7 +79,7 @@ __device__ inline long dst_offset(const P& p, long m) {
 // ABL: compile-time ablation mask for tools/v4_diag (the library only instantiates ABL = 0): 1 no DMA inside the loop, 2 no MFMA,
 // 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores,
 // 128 no s_setprio around the MFMA clusters, 128 + 256 priority to the loading wave instead.
-template <int ABL>
+template <int ABL, typename T = bf16_t>
 __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -226,8 +226,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
-          acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[bh][j][kb]),
-                                                                       __builtin_bit_cast(bf16x8, afr[i][kb]), acc[ah][bh][i][j], 0, 0, 0);
+          acc[ah][bh][i][j] = mfma_16x16x32<T>(bfr[bh][j][kb], afr[i][kb], acc[ah][bh][i][j]);
       if (kb == 0) {
         __builtin_amdgcn_sched_barrier(0);
         mid();
@@ -374,13 +373,13 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
             else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
             v[e] = u;
           }
-          uint2 w2 = {dy_epi::pack2(v[0], v[1]), dy_epi::pack2(v[2], v[3])};
+          uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
           *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
         }
     }
   __syncthreads();
   if (!(ABL & 64))
-    dy_epi::store_rows<BM, BN, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
+    dy_epi::store_rows<BM, BN, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
                                   [&](long m) { return dst_offset(p, m); });
   if (p.stats && !(ABL & 512)) {
     __syncthreads();
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 // tile (K >= 512; shorter ones and the narrower layers go to conv_v5.hip, two smaller blocks per CU) and the tiles fill most of
 // the chip (one block per CU).
 static int v4_variant(const dy_conv_desc* d, int mode) {
-  if (d->dtype != DY_BF16) return 0;
+  if (d->dtype != DY_BF16 && d->dtype != DY_F16) return 0;
   if (!(d->Cs % 64 == 0 && d->KH * d->KW <= 25)) return 0;
   if (mode == 1 && d->stride != 1) return 0;
   if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0) return 0;
@@ -445,7 +444,7 @@ bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode) {
   return !off && v4_variant(d, mode) != 0;
 }
 
-template <int ABL>
+template <int ABL, typename T = bf16_t>
 static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_variant = 0) {
   const int variant = force_variant ? force_variant : v4_variant(d, mode);
   DY_CHECK(variant != 0, "conv_v4: problem not eligible");
@@ -481,7 +480,7 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
   static_assert(SH256 <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4::conv_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, SH256);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4::conv_kernel<ABL, T>), hipFuncAttributeMaxDynamicSharedMemorySize, SH256);
     if (e != hipSuccess) {
       dy_set_error("conv_v4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
@@ -489,11 +488,13 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
     configured = true;
   }
   dy_note_kernel("v4::conv_kernel");
-  v4::conv_kernel<ABL><<<p.nblk, 512, SH256, (hipStream_t)stream>>>(p);
+  v4::conv_kernel<ABL, T><<<p.nblk, 512, SH256, (hipStream_t)stream>>>(p);
   DY_LAUNCH_CHECK();
   return 0;
 }
 
 #ifndef DY_V4_DIAG_BUILD
-int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream) { return v4_launch<0>(d, mode, stream); }
+int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream) {
+  return d->dtype == DY_F16 ? v4_launch<0, f16_t>(d, mode, stream) : v4_launch<0, bf16_t>(d, mode, stream);
+}
 #endif

@@ -68,7 +68,7 @@ __device__ inline long dst_offset(const P& p, long m) {
 }
 
 // BN = 128: waves 2 (M) x 2 (N), wave tile 128 x 64.  BN = 64 (the 64-channel layers): waves 4 x 1, wave tile 64 x 64.
-template <int BN>
+template <int BN, typename T = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, NB = 4, STAGE = A_BYTES + BN * 64, B_LD = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 #pragma unroll
       for (int j = 0; j < NB; ++j)
         // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]), __builtin_bit_cast(bf16x8, afr[i]), acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma_16x16x32<T>(bfr[j], afr[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     cur = cur == 2 * STAGE ? 0 : cur + STAGE;
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
         else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
         v[e] = u;
       }
-      uint2 w2 = {dy_epi::pack2(v[0], v[1]), dy_epi::pack2(v[2], v[3])};
+      uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
       *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
     }
   }
   __syncthreads();
-  dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<bf16_t*>(p.dst),
+  dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
                                 [&](long m) { return dst_offset(p, m); });
   if (p.stats) {
     __syncthreads();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 
 bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
   static const bool off = getenv("DY_NO_CONV_V5") != nullptr;
-  if (off || d->dtype != DY_BF16) return false;
+  if (off || (d->dtype != DY_BF16 && d->dtype != DY_F16)) return false;
   if (!(d->Cs % 32 == 0 && d->KH * d->KW <= 25)) return false;
   if (mode == 1 && d->stride != 1) return false;
   if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0) return false;
@@ -325,20 +325,25 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024, "two blocks per CU");
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
     if (e != hipSuccess) {
       dy_set_error("conv_v5: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
     }
     configured = true;
   }
+  const bool f16 = d->dtype == DY_F16;
   if (bn == 128) {
     dy_note_kernel("v5::conv_kernel<128>");
-    v5::conv_kernel<128><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
+    if (f16) v5::conv_kernel<128, f16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
+    else v5::conv_kernel<128, bf16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
   } else {
     dy_note_kernel("v5::conv_kernel<64>");
-    v5::conv_kernel<64><<<p.nblk, 256, SH64, (hipStream_t)stream>>>(p);
+    if (f16) v5::conv_kernel<64, f16_t><<<p.nblk, 256, SH64, (hipStream_t)stream>>>(p);
+    else v5::conv_kernel<64, bf16_t><<<p.nblk, 256, SH64, (hipStream_t)stream>>>(p);
   }
   DY_LAUNCH_CHECK();
   return 0;

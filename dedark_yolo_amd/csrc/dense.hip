@@ -91,6 +91,9 @@ int dy_dense_fwd_launch(const dy_conv_desc* d, void* stream) {
   if (d->dtype == DY_F32)
     dense_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)d->src, x_img, (const float*)d->w, (float*)d->dst, d->dst_ld, d->N, K, d->Cd,
                                                   d->scale, d->shift, d->act);
+  else if ((d->dtype) == DY_F16)
+    dense_fwd_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)d->src, x_img, (const f16_t*)d->w, (f16_t*)d->dst, d->dst_ld, d->N, K,
+                                                   d->Cd, d->scale, d->shift, d->act);
   else
     dense_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)d->src, x_img, (const bf16_t*)d->w, (bf16_t*)d->dst, d->dst_ld, d->N, K,
                                                    d->Cd, d->scale, d->shift, d->act);
@@ -110,6 +113,9 @@ int dy_dense_dgrad_launch(const dy_conv_desc* d, void* stream) {
   if (d->dtype == DY_F32)
     dense_dgrad_kernel<float><<<grid, 256, 0, st>>>((const float*)d->src, d->src_ld, (const float*)d->w, (float*)d->dst, d->dst_ld, d->N, HW,
                                                     d->Cd, d->Cs, d->accumulate);
+  else if ((d->dtype) == DY_F16)
+    dense_dgrad_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)d->src, d->src_ld, (const f16_t*)d->w, (f16_t*)d->dst, d->dst_ld, d->N,
+                                                     HW, d->Cd, d->Cs, d->accumulate);
   else
     dense_dgrad_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const bf16_t*)d->w, (bf16_t*)d->dst, d->dst_ld, d->N,
                                                      HW, d->Cd, d->Cs, d->accumulate);
@@ -128,6 +134,8 @@ int dy_dense_wgrad_launch(const void* x, long x_ld, int N, int Hi, int Wi, int C
   const unsigned grid = (unsigned)(((long)Cout * HW * Cin_pad + 255) / 256);
   if (dtype == DY_F32)
     dense_wgrad_kernel<float><<<grid, 256, 0, st>>>((const float*)x, x_ld, (const float*)dz, dz_ld, g_oihw, N, HW, Cin, Cin_pad, Cout);
+  else if ((dtype) == DY_F16)
+    dense_wgrad_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, x_ld, (const f16_t*)dz, dz_ld, g_oihw, N, HW, Cin, Cin_pad, Cout);
   else
     dense_wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, x_ld, (const bf16_t*)dz, dz_ld, g_oihw, N, HW, Cin, Cin_pad, Cout);
   DY_LAUNCH_CHECK();

@@ -6,16 +6,20 @@
 
 #define DY_F32 0
 #define DY_BF16 1
+#define DY_F16 2
 
 #define DY_ACT_NONE 0
 #define DY_ACT_SILU 1
 #define DY_ACT_LEAKY 2   // LeakyReLU(0.1)
 
 typedef uint16_t bf16_t;   // raw bf16 bits
+typedef _Float16 f16_t;    // IEEE half (the reference's AMP dtype, BASELINE configs[4])
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 // ---- error plumbing (C-ABI returns int, message via dy_last_error) -------------------------------------------
 extern "C" const char* dy_last_error(void);
@@ -75,6 +79,37 @@ template <> struct DT<bf16_t> {
   __device__ static inline void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+template <> struct DT<f16_t> {
+  static constexpr int id = DY_F16;
+  static constexpr int VE = 8;
+  __device__ static inline float ld(const f16_t* p) { return (float)*p; }
+  __device__ static inline void st(f16_t* p, float v) { *p = (f16_t)v; }
+};
+
+// f32 -> 16-bit storage bits of T / back (the pipelined kernels move 16-bit payloads as raw bits)
+template <typename T> __device__ inline uint16_t cvt16(float f);
+template <> __device__ inline uint16_t cvt16<bf16_t>(float f) { return f32_to_bf16(f); }
+template <> __device__ inline uint16_t cvt16<f16_t>(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
+template <typename T> __device__ inline float cvt32(uint16_t v);
+template <> __device__ inline float cvt32<bf16_t>(uint16_t v) { return bf16_to_f32(v); }
+template <> __device__ inline float cvt32<f16_t>(uint16_t v) { return (float)__builtin_bit_cast(f16_t, v); }
+
+// the two MFMA shapes of the 16-bit kernels, by storage type (8 K-elements per lane and operand, f32 accumulate)
+template <typename T, typename V> __device__ inline f32x16 mfma_32x32x16(V a, V b, f32x16 c) {
+  static_assert(sizeof(V) == 16, "8 x 16-bit operand");
+  if constexpr (sizeof(T) == 2 && !__is_same(T, f16_t))
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <typename T, typename V> __device__ inline f32x4 mfma_16x16x32(V a, V b, f32x4 c) {
+  static_assert(sizeof(V) == 16, "8 x 16-bit operand");
+  if constexpr (sizeof(T) == 2 && !__is_same(T, f16_t))
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // 16-byte vector load/store of VE elements into/out of float registers
 template <typename T> __device__ inline void ldvec(const T* p, float* out);
 template <> __device__ inline void ldvec<float>(const float* p, float* out) {
@@ -89,6 +124,11 @@ template <> __device__ inline void ldvec<bf16_t>(const bf16_t* p, float* out) {
     out[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
   }
 }
+template <> __device__ inline void ldvec<f16_t>(const f16_t* p, float* out) {
+  const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
 template <typename T> __device__ inline void stvec(T* p, const float* in);
 template <> __device__ inline void stvec<float>(float* p, const float* in) {
   f32x4 v = {in[0], in[1], in[2], in[3]};
@@ -100,6 +140,13 @@ template <> __device__ inline void stvec<bf16_t>(bf16_t* p, const float* in) {
   for (int i = 0; i < 4; ++i)
     v[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
   *reinterpret_cast<u32x4*>(p) = v;
+}
+
+template <> __device__ inline void stvec<f16_t>(f16_t* p, const float* in) {
+  f16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (f16_t)in[i];
+  *reinterpret_cast<f16x8*>(p) = v;
 }
 
 // ---- activations ---------------------------------------------------------------------------------------------

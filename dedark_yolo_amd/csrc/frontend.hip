@@ -290,6 +290,7 @@ extern "C" int dy_image_to_nhwc8(const float* x, int B, int H, int W, void* y, i
   DY_CHECK(x && y && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dy_image_to_nhwc8: bad args");
   const int blocks = ew_blocks((long)B * Ho * Wo);
   if (dtype == DY_F32) image_to_nhwc8_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(x, B, H, W, (float*)y, Ho, Wo);
+  else if ((dtype) == DY_F16) image_to_nhwc8_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(x, B, H, W, (f16_t*)y, Ho, Wo);
   else image_to_nhwc8_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(x, B, H, W, (bf16_t*)y, Ho, Wo);
   DY_LAUNCH_CHECK();
   return 0;

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 
 int make_maps(const dy_det_maps* d, Maps& m, const char* who) {
   DY_CHECK(d && d->n_levels >= 1 && d->n_levels <= 3, "%s: bad maps", who);
-  DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16, "%s: bad dtype", who);
+  DY_CHECK(d->dtype == DY_F32 || d->dtype == DY_BF16 || d->dtype == DY_F16, "%s: bad dtype", who);
   m.B = d->B; m.nc = d->nc; m.nl = d->n_levels;
   m.dec_scores = nullptr; m.dec_anchors = nullptr;
   int off = 0;
@@ -692,6 +692,7 @@ extern "C" int dy_loss_decode(const dy_det_maps* d, float* pred_boxes, void* str
   DY_CHECK(pred_boxes, "dy_loss_decode: null");
   int blocks = dy_cdiv((long)m.B * m.A, 256);
   if (d->dtype == DY_F32) decode_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes);
+  else if ((d->dtype) == DY_F16) decode_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes);
   else decode_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes);
   DY_LAUNCH_CHECK();
   return 0;
@@ -719,6 +720,7 @@ int run_assigner(const Maps& m, int dtype, const float* pred_boxes, const float*
   (void)hipMemsetAsync(work_f, 0, (2 * R + 2L * m.B * n_max) * sizeof(float), st);
   dim3 grid(n_max, m.B);
   if (dtype == DY_F32) tal_metrics_kernel<float><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
+  else if ((dtype) == DY_F16) tal_metrics_kernel<f16_t><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
   else tal_metrics_kernel<bf16_t><<<grid, 256, 0, st>>>(m, pred_boxes, gt, n_max, align, overl, work_i, work_b);
   DY_LAUNCH_CHECK();
   int blocks = dy_cdiv(BA, 256);
@@ -767,6 +769,7 @@ extern "C" int dy_loss_fwd(const dy_det_maps* d, const float* pred_boxes, const 
   int blocks = dy_cdiv((long)m.B * m.A, 256);
   if (blocks > 256) blocks = 256;
   if (d->dtype == DY_F32) loss_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes, fg_mask, norm, target_label, target_box, acc);
+  else if ((d->dtype) == DY_F16) loss_fwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes, fg_mask, norm, target_label, target_box, acc);
   else loss_fwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, pred_boxes, fg_mask, norm, target_label, target_box, acc);
   DY_LAUNCH_CHECK();
   return 0;
@@ -800,10 +803,73 @@ extern "C" int dy_loss_bwd(const dy_det_maps* d, void* const dmap[3], const int6
     loss_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(m, dp[0], dp[1], dp[2], dl[0], dl[1], dl[2], pred_boxes, fg_mask,
                                                                     norm, target_label, target_box, acc, grad_out, hyp_box, hyp_cls,
                                                                     hyp_dfl, pad_to);
+  else if ((d->dtype) == DY_F16)
+    loss_bwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, dp[0], dp[1], dp[2], dl[0], dl[1], dl[2], pred_boxes, fg_mask,
+                                                                     norm, target_label, target_box, acc, grad_out, hyp_box,
+                                                                     hyp_cls, hyp_dfl, pad_to);
   else
     loss_bwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, dp[0], dp[1], dp[2], dl[0], dl[1], dl[2], pred_boxes, fg_mask,
                                                                      norm, target_label, target_box, acc, grad_out, hyp_box,
                                                                      hyp_cls, hyp_dfl, pad_to);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the two box-loss terms as stand-alone entries (reference API: metrics.bbox_iou(b1, b2, xywh=False, CIoU=True) and
+// BboxLoss._df_loss(pred_dist, target)); the fused loss kernels above inline the same dy_lossmath.h functions
+__global__ __launch_bounds__(256) void ciou_pairs_kernel(const float* __restrict__ b1, const float* __restrict__ b2, long n,
+                                                         float* __restrict__ out, float* __restrict__ grad_b1) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a[4], b[4], g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a[k] = b1[i * 4 + k]; b[k] = b2[i * 4 + k]; }
+  if (grad_b1) {
+    out[i] = dy_ciou_grad(a, b, g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) grad_b1[i * 4 + k] = g[k];
+  } else {
+    out[i] = dy_ciou(a, b);
+  }
+}
+
+// one thread per (box, side): CE at floor(t) / floor(t)+1 of 16 logits; out[box] = mean over the 4 sides (sides add up through
+// a wave shuffle: 4 neighbouring lanes), grad = d sum(out) / d logits
+__global__ __launch_bounds__(256) void dfl_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, long n_sides,
+                                                  float* __restrict__ out, float* __restrict__ grad) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  float v = 0.f;
+  if (i < n_sides) {
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = pred[i * 16 + k];
+    float wl;
+    int tl;
+    v = dy_dfl_side(x, tgt[i], &wl, &tl);
+    if (grad) {
+      float p[16];
+      dy_softmax_expect(x, 16, p);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) grad[i * 16 + k] = 0.25f * (p[k] - (k == tl ? wl : 0.f) - (k == tl + 1 ? 1.f - wl : 0.f));
+    }
+  }
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  if (i < n_sides && (i & 3) == 0) out[i >> 2] = 0.25f * v;
+}
+
+extern "C" int dy_bbox_ciou(const float* b1, const float* b2, int64_t n, float* out, float* grad_b1, void* stream) {
+  DY_CHECK(n >= 0 && (n == 0 || (b1 && b2 && out)), "dy_bbox_ciou: null operand");
+  if (n == 0) return 0;
+  ciou_pairs_kernel<<<dy_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(b1, b2, n, out, grad_b1);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dy_dfl_loss(const float* pred_dist, const float* target, int64_t n_boxes, float* out, float* grad, void* stream) {
+  DY_CHECK(n_boxes >= 0 && (n_boxes == 0 || (pred_dist && target && out)), "dy_dfl_loss: null operand");
+  if (n_boxes == 0) return 0;
+  dfl_kernel<<<dy_cdiv(n_boxes * 4, 256), 256, 0, (hipStream_t)stream>>>(pred_dist, target, n_boxes * 4, out, grad);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -814,6 +880,7 @@ extern "C" int dy_detect_decode(const dy_det_maps* d, float* y, void* stream) {
   DY_CHECK(y, "dy_detect_decode: null");
   int blocks = dy_cdiv((long)m.B * m.A, 256);
   if (d->dtype == DY_F32) detect_decode_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(m, y);
+  else if ((d->dtype) == DY_F16) detect_decode_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, y);
   else detect_decode_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(m, y);
   DY_LAUNCH_CHECK();
   return 0;

@@ -23,18 +23,33 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomic_add_f64(acc, (double)s);
 }
 
-__device__ inline float clip_coef(const double* sumsq, float max_norm) {
-  if (!sumsq) return 1.f;
-  float nrm = (float)sqrt(*sumsq);
-  float c = max_norm / (nrm + 1e-6f);
-  return c < 1.f ? c : 1.f;
+// Coefficient applied to every gradient element: clip factor min(1, max_norm / (|g| + 1e-6)) on the TRUE norm, times 1 / loss_scale
+// when the gradients were produced from a scaled loss (fp16, reference GradScaler: unscale_ -> clip -> step).  *skip = the scaled
+// gradients hold an inf / NaN: the reference's scaler.step() then leaves parameters and optimizer state untouched.
+__device__ inline float step_coef(const double* sumsq, float max_norm, const float* loss_scale, bool* skip) {
+  const float inv = loss_scale ? 1.f / loss_scale[0] : 1.f;
+  *skip = false;
+  if (!sumsq) return inv;
+  const double ss = *sumsq;
+  if (loss_scale && !(ss < (double)INFINITY)) {
+    *skip = true;
+    return 0.f;
+  }
+  const float nrm = (float)sqrt(ss) * inv;
+  const float c = max_norm / (nrm + 1e-6f);
+  return (c < 1.f ? c : 1.f) * inv;
 }
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ ema,
                            const uint8_t* __restrict__ gid, Hyp h, float mom, int nesterov, float ed, const double* sumsq,
-                           float max_norm, float gscale, long n) {
-  const float cc = clip_coef(sumsq, max_norm) * gscale;
+                           float max_norm, float gscale, const float* loss_scale, long n) {
+  bool skip;
+  const float cc = step_coef(sumsq, max_norm, loss_scale, &skip) * gscale;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (skip) {
+      if (ema) ema[i] = ed * ema[i] + (1.f - ed) * p[i];
+      continue;
+    }
     const int k = gid ? (gid[i] & 3) : 0;
     float w = p[i];
     float d = g[i] * cc + h.wd[k] * w;
@@ -49,9 +64,15 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                              float* __restrict__ ema, const uint8_t* __restrict__ gid, Hyp h, float b1, float b2, float eps,
-                             float bc1, float bc2, float ed, const double* sumsq, float max_norm, float gscale, long n) {
-  const float cc = clip_coef(sumsq, max_norm) * gscale;
+                             float bc1, float bc2, float ed, const double* sumsq, float max_norm, float gscale,
+                             const float* loss_scale, long n) {
+  bool skip;
+  const float cc = step_coef(sumsq, max_norm, loss_scale, &skip) * gscale;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (skip) {
+      if (ema) ema[i] = ed * ema[i] + (1.f - ed) * p[i];
+      continue;
+    }
     const int k = gid ? (gid[i] & 3) : 0;
     float w = p[i] * (1.f - h.lr[k] * h.wd[k]);
     float gi = g[i] * cc;
@@ -63,6 +84,23 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     w -= (h.lr[k] / bc1) * a / denom;
     p[i] = w;
     if (ema) ema[i] = ed * ema[i] + (1.f - ed) * w;
+  }
+}
+
+// dynamic loss scale (torch.cuda.amp.GradScaler.update: growth 2, backoff 0.5, growth_interval 2000): st = {scale, good steps}
+__global__ void loss_scale_update_kernel(float* st, const double* sumsq, float growth, float backoff, int interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (!(*sumsq < (double)INFINITY)) {
+    st[0] *= backoff;
+    st[1] = 0.f;
+  } else {
+    const float good = st[1] + 1.f;
+    if (good >= (float)interval) {
+      st[0] *= growth;
+      st[1] = 0.f;
+    } else {
+      st[1] = good;
+    }
   }
 }
 
@@ -88,14 +126,36 @@ extern "C" int dy_sumsq(const float* g, int64_t n, double* acc, void* stream) {
   return 0;
 }
 
-extern "C" int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1,
-                           float lr2, float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay,
-                           const double* sumsq, float max_norm, float grad_scale, int64_t n, void* stream) {
-  DY_CHECK(p && g && mom_buf && n >= 0, "dy_sgd_step: bad args");
+extern "C" int dy_sgd_step_scaled(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1,
+                                  float lr2, float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay,
+                                  const double* sumsq, float max_norm, float grad_scale, const float* loss_scale, int64_t n,
+                                  void* stream) {
+  DY_CHECK(p && g && mom_buf && n >= 0 && (!loss_scale || sumsq), "dy_sgd_step: bad args");
   if (n == 0) return 0;
   Hyp h = {{lr0, lr1, lr2, lr2}, {wd0, wd1, wd2, wd2}};
   sgd_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, mom_buf, ema, group_id, h, momentum, nesterov, ema_decay, sumsq,
-                                                            max_norm, grad_scale, n);
+                                                            max_norm, grad_scale, loss_scale, n);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1,
+                           float lr2, float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay,
+                           const double* sumsq, float max_norm, float grad_scale, int64_t n, void* stream) {
+  return dy_sgd_step_scaled(p, g, mom_buf, ema, group_id, lr0, lr1, lr2, wd0, wd1, wd2, momentum, nesterov, ema_decay, sumsq, max_norm,
+                            grad_scale, nullptr, n, stream);
+}
+
+extern "C" int dy_adamw_step_scaled(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, const uint8_t* group_id,
+                                    float lr0, float lr1, float lr2, float wd0, float wd1, float wd2, float beta1, float beta2,
+                                    float eps, int step, float ema_decay, const double* sumsq, float max_norm, float grad_scale,
+                                    const float* loss_scale, int64_t n, void* stream) {
+  DY_CHECK(p && g && exp_avg && exp_avg_sq && n >= 0 && step >= 1 && (!loss_scale || sumsq), "dy_adamw_step: bad args");
+  if (n == 0) return 0;
+  Hyp h = {{lr0, lr1, lr2, lr2}, {wd0, wd1, wd2, wd2}};
+  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  adamw_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, exp_avg, exp_avg_sq, ema, group_id, h, beta1, beta2, eps, bc1,
+                                                              bc2, ema_decay, sumsq, max_norm, grad_scale, loss_scale, n);
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -104,12 +164,13 @@ extern "C" int dy_adamw_step(float* p, const float* g, float* exp_avg, float* ex
                              float lr0, float lr1, float lr2, float wd0, float wd1, float wd2, float beta1, float beta2, float eps,
                              int step, float ema_decay, const double* sumsq, float max_norm, float grad_scale, int64_t n,
                              void* stream) {
-  DY_CHECK(p && g && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "dy_adamw_step: bad args");
-  if (n == 0) return 0;
-  Hyp h = {{lr0, lr1, lr2, lr2}, {wd0, wd1, wd2, wd2}};
-  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  adamw_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, exp_avg, exp_avg_sq, ema, group_id, h, beta1, beta2, eps, bc1,
-                                                              bc2, ema_decay, sumsq, max_norm, grad_scale, n);
+  return dy_adamw_step_scaled(p, g, exp_avg, exp_avg_sq, ema, group_id, lr0, lr1, lr2, wd0, wd1, wd2, beta1, beta2, eps, step,
+                              ema_decay, sumsq, max_norm, grad_scale, nullptr, n, stream);
+}
+
+extern "C" int dy_loss_scale_update(float* state, const double* sumsq, float growth, float backoff, int interval, void* stream) {
+  DY_CHECK(state && sumsq && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1, "dy_loss_scale_update: bad args");
+  loss_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, sumsq, growth, backoff, interval);
   DY_LAUNCH_CHECK();
   return 0;
 }

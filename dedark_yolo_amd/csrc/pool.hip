@@ -279,6 +279,7 @@ int check_view(const char* who, const void* p, long ld, int C, int dtype) {
 #define DISPATCH(dtype, KERNEL, grid, ...)                                              \
   do {                                                                                  \
     if ((dtype) == DY_F32) KERNEL<float><<<grid, 256, 0, (hipStream_t)stream>>>(__VA_ARGS__); \
+    else if ((dtype) == DY_F16) KERNEL<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>(__VA_ARGS__);\
     else KERNEL<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(__VA_ARGS__);                  \
     DY_LAUNCH_CHECK();                                                                  \
   } while (0)
@@ -294,6 +295,9 @@ extern "C" int dy_maxpool_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld
   if (dtype == DY_F32)
     maxpool_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, x_ld, (float*)y, y_ld, argmax, N, H, W, C,
                                                                        k, stride, pad, Ho, Wo);
+  else if ((dtype) == DY_F16)
+    maxpool_fwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, x_ld, (f16_t*)y, y_ld, argmax, N, H, W,
+                                                                        C, k, stride, pad, Ho, Wo);
   else
     maxpool_fwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, argmax, N, H, W,
                                                                         C, k, stride, pad, Ho, Wo);
@@ -312,6 +316,9 @@ extern "C" int dy_maxpool_bwd(const void* dy, int64_t dy_ld, const uint8_t* argm
   if (dtype == DY_F32)
     maxpool_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dy, dy_ld, argmax, (float*)dx, dx_ld, N, H, W,
                                                                        C, k, stride, pad, Ho, Wo, accumulate);
+  else if ((dtype) == DY_F16)
+    maxpool_bwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)dy, dy_ld, argmax, (f16_t*)dx, dx_ld, N, H,
+                                                                        W, C, k, stride, pad, Ho, Wo, accumulate);
   else
     maxpool_bwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dy, dy_ld, argmax, (bf16_t*)dx, dx_ld, N, H,
                                                                         W, C, k, stride, pad, Ho, Wo, accumulate);
@@ -328,6 +335,8 @@ extern "C" int dy_upsample_nearest_fwd(const void* x, int64_t x_ld, void* y, int
   const int blocks = ew_blocks((long)N * H * scale * W * scale * (C / ve));
   if (dtype == DY_F32)
     upsample_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, x_ld, (float*)y, y_ld, N, H, W, C, scale);
+  else if ((dtype) == DY_F16)
+    upsample_fwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, x_ld, (f16_t*)y, y_ld, N, H, W, C, scale);
   else
     upsample_fwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, N, H, W, C, scale);
   DY_LAUNCH_CHECK();
@@ -343,6 +352,9 @@ extern "C" int dy_upsample_nearest_bwd(const void* dy, int64_t dy_ld, void* dx, 
   if (dtype == DY_F32)
     upsample_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dy, dy_ld, (float*)dx, dx_ld, N, H, W, C, scale,
                                                                         accumulate);
+  else if ((dtype) == DY_F16)
+    upsample_bwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)dy, dy_ld, (f16_t*)dx, dx_ld, N, H, W, C,
+                                                                         scale, accumulate);
   else
     upsample_bwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dy, dy_ld, (bf16_t*)dx, dx_ld, N, H, W, C,
                                                                          scale, accumulate);
@@ -358,6 +370,9 @@ extern "C" int dy_copy2d(const void* src, int64_t src_ld, void* dst, int64_t dst
   const int blocks = ew_blocks(pixels * (C / ve));
   if (dtype == DY_F32)
     copy2d_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)src, src_ld, (float*)dst, dst_ld, pixels, C, accumulate);
+  else if ((dtype) == DY_F16)
+    copy2d_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)src, src_ld, (f16_t*)dst, dst_ld, pixels, C,
+                                                                   accumulate);
   else
     copy2d_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, src_ld, (bf16_t*)dst, dst_ld, pixels, C,
                                                                    accumulate);
@@ -369,8 +384,11 @@ extern "C" int dy_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
   DY_CHECK(src && dst && n >= 0, "dy_cast: bad args");
   const int blocks = ew_blocks(n);
   hipStream_t st = (hipStream_t)stream;
+  DY_CHECK(src_dtype == dst_dtype || src_dtype == DY_F32 || dst_dtype == DY_F32, "dy_cast: bf16 <-> f16 goes through f32");
   if (src_dtype == DY_F32 && dst_dtype == DY_BF16) cast_kernel<float, bf16_t><<<blocks, 256, 0, st>>>((const float*)src, (bf16_t*)dst, n);
   else if (src_dtype == DY_BF16 && dst_dtype == DY_F32) cast_kernel<bf16_t, float><<<blocks, 256, 0, st>>>((const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == DY_F32 && dst_dtype == DY_F16) cast_kernel<float, f16_t><<<blocks, 256, 0, st>>>((const float*)src, (f16_t*)dst, n);
+  else if (src_dtype == DY_F16 && dst_dtype == DY_F32) cast_kernel<f16_t, float><<<blocks, 256, 0, st>>>((const f16_t*)src, (float*)dst, n);
   else if (src_dtype == DY_F32 && dst_dtype == DY_F32) cast_kernel<float, float><<<blocks, 256, 0, st>>>((const float*)src, (float*)dst, n);
   else cast_kernel<bf16_t, bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n);
   DY_LAUNCH_CHECK();
@@ -393,6 +411,10 @@ extern "C" int dy_asff_fuse_fwd(const void* x0, int64_t ld0, const void* x1, int
   if (dtype == DY_F32)
     asff_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x0, ld0, (const float*)x1, ld1, (const float*)x2, ld2,
                                                                     (const float*)logits, ldl, (float*)out, ldo, pixels, C);
+  else if ((dtype) == DY_F16)
+    asff_fwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x0, ld0, (const f16_t*)x1, ld1,
+                                                                     (const f16_t*)x2, ld2, (const f16_t*)logits, ldl,
+                                                                     (f16_t*)out, ldo, pixels, C);
   else
     asff_fwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x0, ld0, (const bf16_t*)x1, ld1,
                                                                      (const bf16_t*)x2, ld2, (const bf16_t*)logits, ldl,
@@ -423,6 +445,10 @@ extern "C" int dy_asff_fuse_bwd(const void* dout, int64_t lddo, const void* x0, 
     asff_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(
         (const float*)dout, lddo, (const float*)x0, ld0, (const float*)x1, ld1, (const float*)x2, ld2, (const float*)logits, ldl,
         (float*)dx0, ldd0, (float*)dx1, ldd1, (float*)dx2, ldd2, (float*)dlogits, lddl, pixels, C, acc0, acc1, acc2, lgw);
+  else if ((dtype) == DY_F16)
+    asff_bwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(
+        (const f16_t*)dout, lddo, (const f16_t*)x0, ld0, (const f16_t*)x1, ld1, (const f16_t*)x2, ld2, (const f16_t*)logits,
+        ldl, (f16_t*)dx0, ldd0, (f16_t*)dx1, ldd1, (f16_t*)dx2, ldd2, (f16_t*)dlogits, lddl, pixels, C, acc0, acc1, acc2, lgw);
   else
     asff_bwd_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dout, lddo, (const bf16_t*)x0, ld0, (const bf16_t*)x1, ld1, (const bf16_t*)x2, ld2, (const bf16_t*)logits,

@@ -178,8 +178,13 @@ __device__ inline void stage_planar(const S* __restrict__ pl, float* __restrict_
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
       } else {
         const uint2 t = *reinterpret_cast<const uint2*>(row + gx);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        if constexpr (__is_same(S, f16_t)) {
+          v[0] = cvt32<f16_t>((uint16_t)t.x); v[1] = cvt32<f16_t>((uint16_t)(t.x >> 16));
+          v[2] = cvt32<f16_t>((uint16_t)t.y); v[3] = cvt32<f16_t>((uint16_t)(t.y >> 16));
+        } else {
+          v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+          v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        }
       }
     } else {
 #pragma unroll
@@ -352,6 +357,7 @@ extern "C" int dy_usm_fwd(const float* s4, const float* params, float* out_nchw,
   if (int e = ensure_taps()) return e;
   dim3 grid(dy_cdiv(W, TW), dy_cdiv(H, TH), B);
   if (dtype == DY_F32) usm_fwd_kernel<float><<<grid, NTH, 0, (hipStream_t)stream>>>(s4, params, out_nchw, (float*)out_nhwc8, hp, B, H, W);
+  else if ((dtype) == DY_F16) usm_fwd_kernel<f16_t><<<grid, NTH, 0, (hipStream_t)stream>>>(s4, params, out_nchw, (f16_t*)out_nhwc8, hp, B, H, W);
   else usm_fwd_kernel<bf16_t><<<grid, NTH, 0, (hipStream_t)stream>>>(s4, params, out_nchw, (bf16_t*)out_nhwc8, hp, B, H, W);
   DY_LAUNCH_CHECK();
   return 0;
@@ -366,6 +372,8 @@ extern "C" int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc8, int do
   dim3 grid(dy_cdiv(W, TW), dy_cdiv(H, TH), B);
   if (dtype == DY_F32)
     usm_bwd_kernel<float><<<grid, NTH, 0, (hipStream_t)stream>>>(dout_nchw, (const float*)dout_nhwc8, dout_ld, hp, params, ds4, dparams, B, H, W);
+  else if ((dtype) == DY_F16)
+    usm_bwd_kernel<f16_t><<<grid, NTH, 0, (hipStream_t)stream>>>(dout_nchw, (const f16_t*)dout_nhwc8, dout_ld, hp, params, ds4, dparams, B, H, W);
   else
     usm_bwd_kernel<bf16_t><<<grid, NTH, 0, (hipStream_t)stream>>>(dout_nchw, (const bf16_t*)dout_nhwc8, dout_ld, hp, params, ds4, dparams, B, H, W);
   DY_LAUNCH_CHECK();

@@ -49,7 +49,7 @@ struct P {
 };
 
 // BP (k') x 128 (co) block tile on (BP/64) x 2 waves, 64 x 64 outputs per wave, NSTAGE-deep ring of (BP/128 + 1) images.
-template <int BP, int BQ, int NSTAGE>
+template <int BP, int BQ, int NSTAGE, typename T = bf16_t>
 __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
   constexpr int TM = 2, TN = BQ / 64;            // wave tile 64 (k') x BQ/2 (co)
   constexpr int NA = BP / 128;                   // x images per stage
@@ -210,9 +210,7 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           if (a_live[i] && b_live[j])
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
-                                                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[j]),
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
     }
   }
 
@@ -276,13 +274,13 @@ bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
   // padding); DY_WG2_NARROW=<min Cout> overrides for experiments.
   static const int exp_narrow = getenv("DY_WG2_NARROW") ? atoi(getenv("DY_WG2_NARROW")) : 0;
   const int min_co = exp_narrow > 0 ? exp_narrow : 64;
-  return dtype == DY_BF16 && Cin_pad % 8 == 0 && Cout_pad % 8 == 0 && Cout_pad >= min_co && Ktot >= 64 && M >= 4096 && M < (1L << 31) &&
+  return (dtype == DY_BF16 || dtype == DY_F16) && Cin_pad % 8 == 0 && Cout_pad % 8 == 0 && Cout_pad >= min_co && Ktot >= 64 && M >= 4096 && M < (1L << 31) &&
          (x_ld * 2) % 16 == 0 && (dz_ld * 2) % 16 == 0;
 }
 
 int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream) {
+                       long scratch_elems, float* g_oihw, int dtype, void* stream) {
   using namespace wg2;
   // Tile choice (tools/conv_bench, B = 64).  The kernel streams its operands from L2 / Infinity Cache every step, so the tile's
   // flop-per-byte decides: 256 x 256 (128 flop/B, 128 KiB, one block per CU) when the layer has >= 256 output channels
@@ -301,18 +299,19 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   const int BQ = exp_mode == 2 ? 256 : 128;
   const int nstage = exp_mode == 1 ? 3 : 2;      // exp_mode 4: 256 x 128 x 2 stages (96 KiB)
   const int shmem = nstage * (bp / 128 + BQ / 128) * IMG;
-  const void* fn = exp_mode == 1 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 128, 3>)
-                 : exp_mode == 2 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 256, 2>)
-                 : exp_mode == 4 ? reinterpret_cast<const void*>(&wgrad_kernel<256, 128, 2>)
-                                 : reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>);
+  const bool f16 = dtype == DY_F16;
+#define WG2_FN(...) (f16 ? reinterpret_cast<const void*>(&wgrad_kernel<__VA_ARGS__, f16_t>) : reinterpret_cast<const void*>(&wgrad_kernel<__VA_ARGS__, bf16_t>))
+  const void* fn = exp_mode == 1 ? WG2_FN(256, 128, 3) : exp_mode == 2 ? WG2_FN(256, 256, 2) : exp_mode == 4 ? WG2_FN(256, 128, 2) : WG2_FN(128, 128, 2);
+#undef WG2_FN
   static int configured = 0;          // bit mask of the variants whose LDS limit has been raised
-  if (!(configured & (1 << exp_mode))) {
+  const int cfg_bit = 1 << (exp_mode + (f16 ? 8 : 0));
+  if (!(configured & cfg_bit)) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     if (e != hipSuccess) {
       dy_set_error("wgrad_v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
     }
-    configured |= 1 << exp_mode;
+    configured |= cfg_bit;
   }
   const int tiles_p = dy_cdiv(p.Ktot, bp);
   p.tiles_q = dy_cdiv(Cout_pad, BQ);
@@ -336,10 +335,16 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.chunk = chunk;
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel(exp_mode == 2 ? "wg2::wgrad_kernel<256, 256, 2>+reduce_kernel" : (exp_mode == 0 ? "wg2::wgrad_kernel<128, 128, 2>+reduce_kernel" : "wg2::wgrad_kernel<256, 128>+reduce_kernel"));
-  if (exp_mode == 1) wgrad_kernel<256, 128, 3><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
-  else if (exp_mode == 2) wgrad_kernel<256, 256, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
-  else if (exp_mode == 4) wgrad_kernel<256, 128, 2><<<dim3(tiles, (unsigned)splits), 512, shmem, st>>>(p);
-  else wgrad_kernel<128, 128, 2><<<dim3(tiles, (unsigned)splits), 256, shmem, st>>>(p);
+#define WG2_GO(NT_, ...)                                                                              \
+  do {                                                                                                 \
+    if (f16) wgrad_kernel<__VA_ARGS__, f16_t><<<dim3(tiles, (unsigned)splits), NT_, shmem, st>>>(p);   \
+    else wgrad_kernel<__VA_ARGS__, bf16_t><<<dim3(tiles, (unsigned)splits), NT_, shmem, st>>>(p);      \
+  } while (0)
+  if (exp_mode == 1) WG2_GO(512, 256, 128, 3);
+  else if (exp_mode == 2) WG2_GO(512, 256, 256, 2);
+  else if (exp_mode == 4) WG2_GO(512, 256, 128, 2);
+  else WG2_GO(256, 128, 128, 2);
+#undef WG2_GO
   DY_LAUNCH_CHECK();
   reduce_kernel<<<dim3(dy_cdiv(Cout, 32), p.Ktot), 256, 0, st>>>(scratch, (int)splits, tiles, p.tiles_q, bp, BQ, Cout, Cin, Cin_pad,
                                                                             KH, KW, p.Ktot, g_oihw);

@@ -62,7 +62,7 @@ __device__ inline void load_row(const char* src, long ld, int c0, int n, int h, 
   }
 }
 
-template <int CI>
+template <int CI, typename T = bf16_t>
 __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   constexpr int PXB = CI * 2;                           // bytes per x pixel in LDS
   constexpr int CT = CI / 32;                           // ci tiles per tap
@@ -137,9 +137,7 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
-                                                              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bf[j]),
-                                                              acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -195,7 +193,7 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
                           long x_ld, long dz_ld, long scratch_elems) {
   static const bool off = getenv("DY_NO_WGRAD_V3") != nullptr;
   if (off) return false;
-  if (!(dtype == DY_BF16 && (Cin_pad == 64 || Cin_pad == 128) && Cout_pad % 64 == 0 && Cout_pad <= 128 && KH == 3 && KW == 3 && stride == 1 &&
+  if (!((dtype == DY_BF16 || dtype == DY_F16) && (Cin_pad == 64 || Cin_pad == 128) && Cout_pad % 64 == 0 && Cout_pad <= 128 && KH == 3 && KW == 3 && stride == 1 &&
         pad == 1 && dil == 1))
     return false;
   if ((x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
@@ -207,7 +205,7 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
 }
 
 int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
-                       int Cin, float* scratch, long scratch_elems, float* g_oihw, void* stream) {
+                       int Cin, float* scratch, long scratch_elems, float* g_oihw, int dtype, void* stream) {
   using namespace wg3;
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.dz = (const char*)dz; p.dz_ld = dz_ld;
@@ -231,9 +229,11 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
            (long)nblk * ny * slab);
   const int shmem = 4 * p.XW * Cin_pad * 2 + 2 * p.PW * ZPB;
   static int configured = 0;
-  const int bit = Cin_pad == 64 ? 1 : 2;
+  const bool f16 = dtype == DY_F16;
+  const int bit = (Cin_pad == 64 ? 1 : 2) << (f16 ? 2 : 0);
   if (!(configured & bit)) {
-    const void* fn = Cin_pad == 64 ? reinterpret_cast<const void*>(&wgrad_kernel<64>) : reinterpret_cast<const void*>(&wgrad_kernel<128>);
+    const void* fn = Cin_pad == 64 ? (f16 ? reinterpret_cast<const void*>(&wgrad_kernel<64, f16_t>) : reinterpret_cast<const void*>(&wgrad_kernel<64, bf16_t>))
+                                   : (f16 ? reinterpret_cast<const void*>(&wgrad_kernel<128, f16_t>) : reinterpret_cast<const void*>(&wgrad_kernel<128, bf16_t>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dy_set_error("wgrad_v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -243,8 +243,13 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   }
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel(Cin_pad == 64 ? "wg3::wgrad_kernel<64>+reduce_kernel" : "wg3::wgrad_kernel<128>+reduce_kernel");
-  if (Cin_pad == 64) wgrad_kernel<64><<<dim3(nblk, ny), 384, shmem, st>>>(p);
-  else wgrad_kernel<128><<<dim3(nblk, ny), 768, shmem, st>>>(p);
+  if (Cin_pad == 64) {
+    if (f16) wgrad_kernel<64, f16_t><<<dim3(nblk, ny), 384, shmem, st>>>(p);
+    else wgrad_kernel<64, bf16_t><<<dim3(nblk, ny), 384, shmem, st>>>(p);
+  } else {
+    if (f16) wgrad_kernel<128, f16_t><<<dim3(nblk, ny), 768, shmem, st>>>(p);
+    else wgrad_kernel<128, bf16_t><<<dim3(nblk, ny), 768, shmem, st>>>(p);
+  }
   DY_LAUNCH_CHECK();
   reduce_kernel<<<dim3(dy_cdiv(Cout, 32), 9 * Cin_pad), 256, 0, st>>>(scratch, nblk, Cin_pad, Cout, Cin, g_oihw);
   DY_LAUNCH_CHECK();

@@ -61,7 +61,7 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 }
 
 // POINTWISE: 1x1 / stride 1 / no padding: x rows are the output pixels themselves (no gather arithmetic at all).
-template <bool POINTWISE>
+template <bool POINTWISE, typename T = bf16_t>
 __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -251,8 +251,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[i][kb]),
-                                                                       __builtin_bit_cast(bf16x8, bfr[bh][j][kb]), acc[ah][bh][i][j], 0, 0, 0);
+          acc[ah][bh][i][j] = mfma_16x16x32<T>(afr[i][kb], bfr[bh][j][kb], acc[ah][bh][i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, int N, int Hi, int Wi, int Ho, int Wo, long x_ld,
                           long dz_ld, long scratch_elems) {
   static const bool off = getenv("DY_NO_WGRAD_V4") != nullptr;
-  if (off || dtype != DY_BF16) return false;
+  if (off || (dtype != DY_BF16 && dtype != DY_F16)) return false;
   if (Cin_pad % 8 != 0 || Cout_pad % 8 != 0 || (x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
   const long Ktot = (long)KH * KW * Cin_pad;
   const long tq = (Cout_pad + 255) / 256, tp = (Ktot + 255) / 256;
@@ -387,7 +386,7 @@ bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
 
 int dy_wgrad_v4_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Ho, int Wo,
                        int Cout_pad, int KH, int KW, int stride, int pad, int dil, int Cout, int Cin, float* scratch,
-                       long scratch_elems, float* g_oihw, void* stream) {
+                       long scratch_elems, float* g_oihw, int dtype, void* stream) {
   using namespace wg4;
   P p;
   p.x = (const char*)x; p.dz = (const char*)dz; p.x_ld = x_ld; p.dz_ld = dz_ld;
@@ -418,8 +417,10 @@ int dy_wgrad_v4_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   constexpr int SHMEM = 2 * BUF;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<false, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<true, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<false, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<true, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) {
       dy_set_error("wgrad_v4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
@@ -428,8 +429,13 @@ int dy_wgrad_v4_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   }
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel("wg4::wgrad_kernel+reduce_kernel");
-  if (pointwise) wgrad_kernel<true><<<p.nblk, 512, SHMEM, st>>>(p);
-  else wgrad_kernel<false><<<p.nblk, 512, SHMEM, st>>>(p);
+  if (dtype == DY_F16) {
+    if (pointwise) wgrad_kernel<true, f16_t><<<p.nblk, 512, SHMEM, st>>>(p);
+    else wgrad_kernel<false, f16_t><<<p.nblk, 512, SHMEM, st>>>(p);
+  } else {
+    if (pointwise) wgrad_kernel<true, bf16_t><<<p.nblk, 512, SHMEM, st>>>(p);
+    else wgrad_kernel<false, bf16_t><<<p.nblk, 512, SHMEM, st>>>(p);
+  }
   DY_LAUNCH_CHECK();
   reduce_kernel<<<dim3(dy_cdiv(Cin, 256), Cout), 256, 0, st>>>(scratch, (int)splits, p.tiles, p.tiles_q, Cout, Cin, Cin_pad, KH * KW, g_oihw);
   DY_LAUNCH_CHECK();

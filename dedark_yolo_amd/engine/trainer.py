@@ -228,7 +228,13 @@ class DetectionTrainer:
 
     def setup(self, model=None, nc=None, total_iterations=None):
         torch.cuda.set_device(self.device)
-        ops.set_compute_dtype(torch.bfloat16 if str(getattr(self.args, "dtype", "fp32")) in ("bf16", "bfloat16") else torch.float32)
+        dt = str(getattr(self.args, "dtype", "fp32"))
+        self.compute_dtype = (torch.bfloat16 if dt in ("bf16", "bfloat16") else
+                              torch.float16 if dt in ("fp16", "float16", "half") else torch.float32)
+        ops.set_compute_dtype(self.compute_dtype)
+        # fp16 = the reference's AMP (trainer.py:221 GradScaler): dynamic loss scale kept ON THE DEVICE, {scale, finite steps}
+        self.loss_scale = (torch.tensor([65536.0, 0.0], dtype=torch.float32, device=self.device)
+                           if self.compute_dtype == torch.float16 else None)
         self.model = (model if model is not None else self.get_model(nc=nc)).to(self.device)
         self.model.args = self.args
         self.model.train()
@@ -315,12 +321,15 @@ class DetectionTrainer:
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000))                       # torch_utils.py:357
         wd = self.weight_decay
+        ls = getattr(self, "loss_scale", None)      # fp16: unscale inside the step, skip it on overflow, then GradScaler.update
         if self.opt_name == "AdamW":
-            call("dy_adamw_step", ptr(f.p), ptr(g), ptr(f.m), ptr(f.m2), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0,
-                 mom, 0.999, 1e-8, self.updates, d, ptr(f.sumsq), 10.0, 1.0, f.n, st)
+            call("dy_adamw_step_scaled", ptr(f.p), ptr(g), ptr(f.m), ptr(f.m2), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0,
+                 mom, 0.999, 1e-8, self.updates, d, ptr(f.sumsq), 10.0, 1.0, ptr(ls), f.n, st)
         else:
-            call("dy_sgd_step", ptr(f.p), ptr(g), ptr(f.m), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0, mom, 1, d,
-                 ptr(f.sumsq), 10.0, 1.0, f.n, st)
+            call("dy_sgd_step_scaled", ptr(f.p), ptr(g), ptr(f.m), ptr(f.ema), ptr(f.gid), lr[0], lr[1], lr[2], wd, 0.0, 0.0, mom, 1, d,
+                 ptr(f.sumsq), 10.0, 1.0, ptr(ls), f.n, st)
+        if ls is not None:
+            call("dy_loss_scale_update", ptr(ls), ptr(f.sumsq), 2.0, 0.5, 2000, st)
         if f.buf_ema is not None and f.buf_flat.numel():
             call("dy_ema_lerp", ptr(f.buf_ema), ptr(f.buf_flat), d, f.buf_flat.numel(), st)
         if self.acc_count > 0:
@@ -342,7 +351,10 @@ class DetectionTrainer:
         step_optimizer=False only accumulates the gradients (trainer.py:340-342)."""
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
-        loss.backward()
+        if getattr(self, "loss_scale", None) is not None:
+            (loss * self.loss_scale[0]).backward()      # scaler.scale(loss).backward() (trainer.py:340)
+        else:
+            loss.backward()
         ops.wgrad_join()
         if self.buckets is not None:
             self.buckets.finish()

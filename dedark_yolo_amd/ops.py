@@ -18,8 +18,11 @@ _weights_epoch = 0          # bumped by the fused optimizer (it writes parameter
 
 
 def set_compute_dtype(dt):
+    """fp32 = the parity path (exact-f32 MFMA), bf16 = the throughput path, fp16 = the reference's AMP dtype (BASELINE configs[4];
+    the trainer adds dynamic loss scaling)."""
     global _compute_dtype
-    assert dt in (torch.float32, torch.bfloat16)
+    if dt not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError(f"dedark_yolo_amd: unsupported compute dtype {dt}")
     _compute_dtype = dt
 
 
@@ -37,6 +40,8 @@ def dt_id(dtype):
         return _C.DY_F32
     if dtype == torch.bfloat16:
         return _C.DY_BF16
+    if dtype == torch.float16:
+        return _C.DY_F16
     raise RuntimeError(f"dedark_yolo_amd: unsupported dtype {dtype}")
 
 

@@ -128,6 +128,38 @@ class _DetLossFn(torch.autograd.Function):
         return (None, None, None, *[d[:, :no] for d in dbufs])
 
 
+class _DFL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_dist, target):
+        n = target.shape[0]
+        out = torch.empty((n, 1), dtype=torch.float32, device=pred_dist.device)
+        grad = torch.empty_like(pred_dist) if pred_dist.requires_grad else None
+        call("dy_dfl_loss", ptr(pred_dist), ptr(target), n, ptr(out), ptr(grad), stream())
+        ctx.grad = grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.grad * g.repeat_interleave(4, 0), None
+
+
+class BboxLoss:
+    """The stand-alone pieces of the reference's BboxLoss (ultralytics/utils/loss.py:54-84); the training step itself computes both
+    terms inside the fused dy_loss_fwd / dy_loss_bwd kernels with the same device functions (csrc/dy_lossmath.h)."""
+
+    def __init__(self, reg_max, use_dfl=False):
+        self.reg_max, self.use_dfl = reg_max, use_dfl
+
+    @staticmethod
+    def _df_loss(pred_dist, target):
+        """pred_dist [n*4, 16] logits, target [n, 4] in [0, 15) -> [n, 1] (mean over the sides of the two-bin cross entropy)."""
+        if pred_dist.device.type != "cuda":
+            raise RuntimeError("_df_loss needs device tensors (there is no CPU path)")
+        if pred_dist.shape[-1] != REG_MAX or pred_dist.shape[0] != target.numel():
+            raise ValueError(f"_df_loss: expected pred_dist [n*4, {REG_MAX}] and target [n, 4]")
+        return _DFL.apply(pred_dist.float().contiguous(), target.float().contiguous().detach())
+
+
 class v8DetectionLoss:
     """reference loss.py:103-193. `model.args` must carry .box/.cls/.dfl (and .lrl for the recovery variant)."""
     use_recovery = False

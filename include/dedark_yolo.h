@@ -8,7 +8,8 @@
  *
  * Layouts: activations are NHWC ("pixel-major"); a tensor view is (pointer to element [n=0,h=0,w=0,c=c0], ld) where
  * `ld` is the pixel stride in ELEMENTS, so a channel slice of a wider concat buffer is a view with ld = total width.
- * dtype: DY_F32 (parity path, exact-f32 MFMA 32x32x2) or DY_BF16 (throughput path, MFMA 32x32x16, f32 accumulate).
+ * dtype: DY_F32 (parity path, exact-f32 MFMA 32x32x2), DY_BF16 (throughput path, MFMA 32x32x16 / 16x16x32, f32 accumulate) or
+ * DY_F16 (IEEE half: the same kernels on the f16 MFMA; the reference's AMP dtype, BASELINE configs[4]).
  * Weights: f32 OIHW master (the reference state_dict layout) is packed per step into [Cout][KH][KW][Cin] ("KRSC").
  */
 #ifndef DEDARK_YOLO_H
@@ -21,6 +22,7 @@ extern "C" {
 
 #define DY_F32 0
 #define DY_BF16 1
+#define DY_F16 2
 #define DY_ACT_NONE 0
 #define DY_ACT_SILU 1
 #define DY_ACT_LEAKY 2 /* LeakyReLU(0.1) */
@@ -53,7 +55,7 @@ typedef struct {
   double* stats;      /* optional [DY_STATS_REPLICAS][2*Cd] zeroed accumulators: (sum, sum of squares) of the RAW conv
                          output over all pixels, spread over replicas to avoid atomic contention (BN batch stats) */
   int accumulate;     /* 1: dst += result */
-  int dtype;          /* DY_F32 | DY_BF16 (src, w, dst) */
+  int dtype;          /* DY_F32 | DY_BF16 | DY_F16 (src, w, dst) */
   /* optional extensions, all zero = dense destination / full window (a zero-initialised descriptor keeps the old meaning) */
   int64_t dst_row_stride; /* elements between destination rows    (0: Wd * dst_ld) */
   int64_t dst_img_stride; /* elements between destination images  (0: Hd * row stride) */
@@ -211,6 +213,12 @@ int dy_tal_assign_decoded(const float* pd_scores, const float* pd_bboxes, const 
                           const int32_t* counts, int B, int A, int nc, int n_max, float* work_f, int32_t* work_i, uint8_t* work_b,
                           int32_t* target_gt_idx, uint8_t* fg_mask, float* norm, int32_t* target_label, float* target_box,
                           void* stream);
+/* CIoU of n box pairs, xyxy f32 (reference ultralytics/utils/metrics.py:75-128 bbox_iou(b1, b2, xywh=False, CIoU=True): eps added to
+ * h only, alpha constant in the backward); grad_b1 (nullable) [n,4] = d out[i] / d b1[i]. */
+int dy_bbox_ciou(const float* b1, const float* b2, int64_t n, float* out, float* grad_b1, void* stream);
+/* Distribution focal loss (reference ultralytics/utils/loss.py:75-84 BboxLoss._df_loss): pred_dist [n_boxes*4, 16] logits,
+ * target [n_boxes, 4] in [0, 15); out [n_boxes] = mean over the 4 sides; grad (nullable) = d sum(out) / d pred_dist. */
+int dy_dfl_loss(const float* pred_dist, const float* target, int64_t n_boxes, float* out, float* grad, void* stream);
 /* loss sums: acc[0]=sum target_scores, acc[1]=BCE sum, acc[2]=sum (1-ciou)*w, acc[3]=sum dfl*w (acc zeroed first) */
 int dy_loss_fwd(const dy_det_maps* m, const float* pred_boxes, const uint8_t* fg_mask, const float* norm,
                 const int32_t* target_label, const float* target_box, double* acc, void* stream);
@@ -261,6 +269,19 @@ int dy_sgd_step(float* p, const float* g, float* mom_buf, float* ema, const uint
 int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, const uint8_t* group_id, float lr0,
                   float lr1, float lr2, float wd0, float wd1, float wd2, float beta1, float beta2, float eps, int step,
                   float ema_decay, const double* sumsq, float max_norm, float grad_scale, int64_t n, void* stream);
+/* fp16 training (reference AMP: torch.cuda.amp.GradScaler, U/engine/trainer.py:221,330,340,459-467).  The loss gradient is
+ * multiplied by loss_scale[0] before the backward pass; the *_scaled steps divide it out again (clip on the TRUE norm), and leave
+ * parameters and optimizer state untouched when *sumsq is inf / NaN (the EMA is still updated, as trainer.optimizer_step does).
+ * dy_loss_scale_update then applies GradScaler.update to state = {scale, consecutive finite steps}: scale *= backoff after an
+ * overflow, scale *= growth after `interval` finite steps.  loss_scale == NULL: exactly dy_sgd_step / dy_adamw_step. */
+int dy_sgd_step_scaled(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1, float lr2,
+                       float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay, const double* sumsq,
+                       float max_norm, float grad_scale, const float* loss_scale, int64_t n, void* stream);
+int dy_adamw_step_scaled(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* ema, const uint8_t* group_id, float lr0,
+                         float lr1, float lr2, float wd0, float wd1, float wd2, float beta1, float beta2, float eps, int step,
+                         float ema_decay, const double* sumsq, float max_norm, float grad_scale, const float* loss_scale, int64_t n,
+                         void* stream);
+int dy_loss_scale_update(float* state, const double* sumsq, float growth, float backoff, int interval, void* stream);
 /* ema = decay*ema + (1-decay)*src (EMA of the BatchNorm running buffers) */
 int dy_ema_lerp(float* ema, const float* src, float decay, int64_t n, void* stream);
 /* acc += g: gradient accumulation over `accumulate` batches (nbs / batch, U/engine/trainer.py:248,340-342) */

@@ -104,6 +104,10 @@ def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch
             e = float((g - tgt).norm()) / den if den > 1e-10 else float((g - tgt).norm())
             eo = (float((r - tgt).norm()) / den if den > 1e-10 else float((r - tgt).norm())) if ref64 is not None else 0.0
             errs.append((e, eo, k))
+        # direction of the whole step: cosine between the concatenated gradients
+        dots = [(float((p.grad.detach().double().cpu() * sd[k].grad.double()).sum()), float(p.grad.detach().double().norm()) ** 2,
+                 float(sd[k].grad.double().norm()) ** 2) for k, p in named.items() if p.grad is not None and sd[k].grad is not None]
+        out["grad_cosine"] = sum(d[0] for d in dots) / max((sum(d[1] for d in dots) * sum(d[2] for d in dots)) ** 0.5, 1e-300)
         errs.sort(reverse=True)
         out["worst_grad_rel"] = errs[0][0]
         out["worst_grad_key"] = errs[0][2]

@@ -26,8 +26,11 @@ def _err(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
 
 
-def _case(dtype, B, Cin, Cout, H, W, k, s, p, d=1):
-    from dedark_yolo_amd import ops
+def _case(dtype, B, Cin, Cout, H, W, k, s, p, d=1, routes=None):
+    """`routes`: dict that receives {C-ABI entry: GPU kernel symbol it launched} (dy_last_kernel) for the route assertions."""
+    from dedark_yolo_amd import _C, ops
+    if routes is not None:
+        _C._prof = []
     torch.manual_seed(B * 1000 + Cin + Cout + H)
     x = torch.randn(B, Cin, H, W, device="cuda")
     kh, kw = k if isinstance(k, tuple) else (k, k)
@@ -47,6 +50,11 @@ def _case(dtype, B, Cin, Cout, H, W, k, s, p, d=1):
     b2 = bias.detach().clone().requires_grad_(True)
     F.conv2d(xr2, wq2, b2, s, p, d).backward(gy.to(dtype).float())
     torch.cuda.synchronize()
+    if routes is not None:
+        for name, _e0, _e1, _meta, kern in _C._prof:
+            if kern:
+                routes[name] = kern
+        _C._prof = None
     return dict(fwd=_err(y, ref), dx=_err(dx, xr2.grad), dw=_err(tape.pgrads[w], wq2.grad), db=_err(tape.pgrads[bias], b2.grad))
 
 
@@ -83,6 +91,47 @@ def test_conv_f32_exact_mfma(shape):
 def test_conv_bf16(shape):
     r = _case(torch.bfloat16, *shape)
     assert max(r.values()) < 1e-2, r
+
+
+# the large-tile kernels only take layers that fill the chip (>= 192 tiles of 256 x 256, >= 256 tiles of 256 x 128 / 256 x 64,
+# >= 16384 pixels for the weight gradient): shape, expected kernel of (forward, data gradient, weight gradient)
+ROUTED = [
+    ((32, 256, 256, 40, 40, 3, 1, 1), ("v4::conv_kernel", "v4::conv_kernel", "wg4::wgrad_kernel")),
+    ((31, 192, 232, 41, 43, 3, 1, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # ragged pixels / channels
+    ((13, 512, 256, 80, 80, 1, 1, 0), ("v4::conv_kernel", "v5::conv_kernel<128>", "wg4::wgrad_kernel")),        # 1x1: K = 512 / K = 256
+    ((20, 256, 512, 80, 80, 3, 2, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # stride 2 (dgrad: parity classes)
+    ((24, 128, 128, 80, 80, 3, 1, 1), ("v5::conv_kernel<128>", "v5::conv_kernel<128>", None)),
+    ((20, 128, 128, 57, 61, 3, 1, 2, 2), ("v5::conv_kernel<128>", "v5::conv_kernel<128>", None)),               # dilated, ragged
+    ((20, 96, 224, 57, 61, 3, 1, 1), ("v5::conv_kernel<128>", None, "wg4::wgrad_kernel")),                      # 96 = 3 x 32 source channels
+    ((12, 64, 64, 160, 160, 3, 1, 1), ("v5::conv_kernel<64>", "v5::conv_kernel<64>", None)),
+    ((8, 320, 128, 160, 160, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),
+    ((6, 64, 256, 63, 65, 5, 1, 2), (None, None, "wg4::wgrad_kernel")),                                         # 5x5 taps in the mixed-radix walk
+    ((8, 1024, 256, 48, 48, 1, 1, 0), (None, None, "wg4::wgrad_kernel")),                                       # pointwise variant
+]
+
+
+@pytest.mark.parametrize("shape,want", ROUTED, ids=lambda v: "x".join(map(str, v)) if isinstance(v[0], int) else None)
+def test_conv_bf16_large_tile_routes(shape, want):
+    """Every large-tile kernel (conv_v4 256x256, conv_v5 256x128 / 256x64, wgrad_v4) on shapes big enough for the dispatch to pick
+    it -- and the test checks that it did (the symbol each C-ABI entry reports), so a routing change cannot silently move these
+    shapes back onto the older kernels.  Same bound as test_conv_bf16."""
+    routes = {}
+    r = _case(torch.bfloat16, *shape, routes=routes)
+    assert max(r.values()) < 1e-2, (r, routes)
+    for entry, sym in zip(("dy_conv2d_fwd", "dy_conv2d_dgrad", "dy_conv2d_wgrad"), want):
+        if sym is not None:
+            assert routes.get(entry, "").startswith(sym), (entry, sym, routes)
+
+
+F16_SHAPES = GENERIC[:9] + PIPELINED[::3] + [r[0] for r in ROUTED[:7]]
+
+
+@pytest.mark.parametrize("shape", F16_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv_f16(shape):
+    """IEEE half (BASELINE configs[4]: the reference's AMP dtype) through the same dispatch: the generic kernel and every pipelined
+    kernel are instantiated for the f16 MFMA.  11-bit mantissa: bound 2e-3 * max|ref| (bf16: 1e-2)."""
+    r = _case(torch.float16, *shape)
+    assert max(r.values()) < 2e-3, r
 
 
 THIN = [(12, 16, 32, 41, 39, 3, 2, 1), (5, 32, 24, 37, 35, 3, 1, 1), (4, 16, 16, 40, 40, 1, 1, 0), (6, 32, 16, 36, 38, 3, 2, 1),

@@ -13,7 +13,7 @@ from util import load_yaml
 pytestmark = pytest.mark.gpu
 
 
-def _tiny_trainer(optimizer, batch=64, **over):
+def _tiny_trainer(optimizer, batch=64, dtype="fp32", **over):
     import dedark_yolo_amd as dy
     from dedark_yolo_amd.engine.trainer import DetectionTrainer, get_cfg
     from dedark_yolo_amd.nn.tasks import DetectionModel
@@ -22,7 +22,7 @@ def _tiny_trainer(optimizer, batch=64, **over):
     cfgd["scales"]["t"] = [0.33, 0.125, 1024]
     cfgd["scale"] = "t"
     torch.manual_seed(3)
-    cfg = get_cfg(dict(model="tiny", dtype="fp32", optimizer=optimizer, batch=batch, lowlight_FLAG=True, dedark_FLAG=True, **over))
+    cfg = get_cfg(dict(model="tiny", dtype=dtype, optimizer=optimizer, batch=batch, lowlight_FLAG=True, dedark_FLAG=True, **over))
     tr = DetectionTrainer(cfg)
     tr.setup(DetectionModel(cfgd, nc=20))
     return tr
@@ -133,16 +133,14 @@ def test_train_loop_steps_optimizer_every_accumulate_batches():
     assert tr.updates - before == 2 and len(hist) == 1 and all(np.isfinite(hist[0]))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
     """End-to-end sanity of the whole path (front-end, network, assigner, loss, backward, clip, SGD, EMA, weight re-pack):
     120 optimizer steps on one fixed synthetic batch must drive the loss down substantially in both compute dtypes (the first
     tens of steps are noisy: batch-4 BatchNorm and a moving assignment; measured 24 -> 7.4 in fp32)."""
     import bench
     import dedark_yolo_amd as dy
-    tr = _tiny_trainer("SGD", batch=64)
-    if dtype == "bf16":
-        dy.set_compute_dtype(torch.bfloat16)
+    tr = _tiny_trainer("SGD", batch=64, dtype=dtype)       # fp16 brings the dynamic loss scale with it
     try:
         b = bench.synth_batch(77, 4, 96, 20, "cuda")
         tr.args.dark_param = b.pop("gamma")
@@ -154,6 +152,52 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
         assert all(np.isfinite(losses)), losses
         first, last = float(np.mean(losses[:10])), float(np.mean(losses[-10:]))
         assert last < 0.6 * first, (first, last)
+        if dtype == "fp16":
+            scale, good = [float(v) for v in tr.loss_scale]
+            assert np.isfinite(scale) and 1.0 <= scale <= 65536.0 and good >= 1, (scale, good)
+    finally:
+        dy.set_compute_dtype(torch.float32)
+
+
+def test_fp16_loss_scale_follows_gradscaler():
+    """The device-side loss scale of the fp16 path against torch.cuda.amp.GradScaler's rules (the reference's AMP,
+    ultralytics/engine/trainer.py:221,459-467): an inf in the scaled gradients skips the update (parameters and momentum
+    untouched, EMA still updated), halves the scale and resets the counter; finite steps unscale before clipping and count up;
+    `growth_interval` finite steps double the scale."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd._C import call
+    from dedark_yolo_amd.ops import ptr, stream
+    tr = _tiny_trainer("SGD", batch=64, dtype="fp16")
+    try:
+        f = tr.flat
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        g_true = torch.randn(f.n, device="cuda", generator=gen) * 1e-3
+        # 1) overflow
+        f.g.copy_(g_true * 65536.0)
+        f.g[7] = float("inf")
+        p0, m0, e0 = f.p.clone(), f.m.clone(), f.ema.clone()
+        tr.optimizer_step([0.01] * 3, 0.9)
+        torch.cuda.synchronize()
+        assert torch.equal(f.p, p0) and torch.equal(f.m, m0), "an overflowed step must not touch parameters / momentum"
+        d = 0.9999 * (1 - math.exp(-tr.updates / 2000))
+        assert torch.allclose(f.ema, d * e0 + (1 - d) * p0, rtol=1e-6, atol=1e-7)
+        assert [float(v) for v in tr.loss_scale] == [32768.0, 0.0]
+        # 2) finite step at scale 32768 == the unscaled step of the plain entry on a twin state
+        f.g.copy_(g_true * 32768.0)
+        twin_p, twin_m = f.p.clone(), f.m.clone()
+        ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        call("dy_sumsq", ptr(g_true), f.n, ptr(ss), stream())
+        call("dy_sgd_step", ptr(twin_p), ptr(g_true), ptr(twin_m), None, ptr(f.gid), 0.01, 0.01, 0.01, tr.weight_decay, 0.0, 0.0, 0.9, 1,
+             0.0, ptr(ss), 10.0, 1.0, f.n, stream())
+        tr.optimizer_step([0.01] * 3, 0.9)
+        torch.cuda.synchronize()
+        assert torch.allclose(f.p, twin_p, rtol=1e-5, atol=1e-8) and torch.allclose(f.m, twin_m, rtol=1e-5, atol=1e-8)
+        assert [float(v) for v in tr.loss_scale] == [32768.0, 1.0]
+        # 3) growth after `interval` finite steps (the update entry alone, interval 3)
+        st = torch.tensor([1024.0, 0.0], device="cuda")
+        for want in ([1024.0, 1.0], [1024.0, 2.0], [2048.0, 0.0]):
+            call("dy_loss_scale_update", ptr(st), ptr(ss), 2.0, 0.5, 3, stream())
+            assert [float(v) for v in st] == want
     finally:
         dy.set_compute_dtype(torch.float32)
 
