@@ -287,6 +287,36 @@ class DetectionModel(BaseModel):
             self.stride = torch.Tensor([32])
         initialize_weights(self)
 
+    @torch.no_grad()
+    def reference_initial_buffers(self, s=256):
+        """Give the BatchNorm buffers the values a freshly constructed REFERENCE model has.  Its constructor probes the strides with
+        two train-mode forward passes of zeros(1, ch, 256, 256) before initialize_weights() sets eps / momentum (tasks.py:284-292,
+        torch_utils.py:257-267), so its running statistics start from two eps-1e-5 / momentum-0.1 updates on the zero image and
+        num_batches_tracked = 2 -- not from (0, 1).  Optional: only a from-scratch run that must follow the reference's own
+        trajectory needs it (checkpoints carry their buffers).  Call after .cuda(); pinned by tests/golden/g10_initbuf.npz."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("reference_initial_buffers() runs two forward passes: move the model to the GPU first")
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        keep = [(m.eps, m.momentum) for m in bns]
+        was_training = self.training
+        dt = ops.get_compute_dtype()
+        ops.set_compute_dtype(torch.float32)          # the reference builds its models in fp32
+        try:
+            for m in bns:
+                m.eps, m.momentum = 1e-5, 0.1
+            self.train()
+            zero = torch.zeros(1, self.yaml.get("ch", 3), s, s, device=dev)
+            for _ in range(2):
+                self._predict_once(zero)
+            ops.flush_bn_counters()
+        finally:
+            for m, (e, mo) in zip(bns, keep):
+                m.eps, m.momentum = e, mo
+            self.train(was_training)
+            ops.set_compute_dtype(dt)
+        return self
+
     def _graph_strides(self):
         s = []
         for L in self.model:

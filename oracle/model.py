@@ -413,3 +413,20 @@ def forward(plan, save, sd, x, train, A=None, IcA=None, want_front=False):
             x = detect(sd, p, x, L["nc"], strides, train)
         ys.append(x if L["i"] in save else None)
     return (x, front) if want_front else x
+
+
+def reference_initial_buffers(plan, save, sd, ch=3, s=256):
+    """State of the BatchNorm buffers of a freshly constructed reference model: DetectionModel.__init__ (tasks.py:284-292) probes
+    the strides with TWO train-mode forward passes of zeros(1, ch, 256, 256) BEFORE initialize_weights() (torch_utils.py:257-267)
+    sets eps = 1e-3 / momentum = 0.03, i.e. with torch's BatchNorm defaults eps = 1e-5 / momentum = 0.1.  Updates `sd` in place
+    (running_mean, running_var, num_batches_tracked); pinned by tests/golden/g10_initbuf.npz."""
+    global BN_EPS, BN_MOM
+    keep = (BN_EPS, BN_MOM)
+    BN_EPS, BN_MOM = 1e-5, 0.1
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                forward(plan, save, sd, torch.zeros(1, ch, s, s), True)
+    finally:
+        BN_EPS, BN_MOM = keep
+    return sd

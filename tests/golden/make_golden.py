@@ -463,10 +463,28 @@ def g_pre():
     save("g9_prenms", **arrs)
 
 
+# ------------------------------------------------------------------ G10: the state a freshly constructed reference model starts from
+def g_initbuf():
+    """DetectionModel.__init__ (nn/tasks.py:284-292) probes the strides with TWO train-mode forward passes of zeros(1, ch, 256, 256)
+    before initialize_weights() sets eps / momentum: the BatchNorm running statistics of a new reference model are therefore not
+    (0, 1) but two momentum-0.1, eps-1e-5 updates on the zero image (num_batches_tracked = 2).  Captured for a tiny plain graph:
+    every parameter (torch's default init under a fixed seed) and every buffer right after construction."""
+    d = yaml_model_load("yolov8nori.yaml")
+    d["scales"]["t"] = [0.33, 0.0625, 1024]
+    d["scale"] = "t"
+    torch.manual_seed(1234)
+    m = DetectionModel(d, ch=3, nc=4, verbose=False)
+    sd = m.state_dict()
+    bn = [k for k in sd if k.endswith("num_batches_tracked")]
+    assert bn and all(int(sd[k]) == 2 for k in bn)
+    save("g10_initbuf", **{k: v for k, v in sd.items()})
+    print("g10_initbuf:", len(sd), "tensors,", sum(v.numel() for v in sd.values()), "elements")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or None
     todo = dict(frontend=g_frontend, blocks=g_blocks, models=g_models, assigner=g_assigner, small=g_small, val=g_val, ckpt=g_ckpt,
-                pre=g_pre, variants=g_variants)
+                pre=g_pre, variants=g_variants, initbuf=g_initbuf)
     for k, fn in todo.items():
         if not ONLY or k in ONLY:
             fn()

@@ -360,3 +360,31 @@ def test_arena_growth_inside_branch_streams():
     assert np.allclose(l1, l0, rtol=2e-5, atol=1e-5), (l1, l0)
     assert float((b1 - b0).abs().max()) <= 1e-5 * max(1.0, float(b0.abs().max()))          # BatchNorm running statistics
     assert float((g1 - g0).abs().max()) <= 2e-4 * max(1e-3, float(g0.abs().max()))
+
+
+def test_reference_initial_bn_buffers_on_gpu():
+    """DetectionModel.reference_initial_buffers() against the buffers of a freshly constructed reference model
+    (tests/golden/g10_initbuf.npz: its constructor's two zero-image probes, tasks.py:284-292)."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from util import close, gold
+    dy.set_compute_dtype(torch.float32)
+    g = gold("g10_initbuf")
+    cfg = load_yaml("yolov8ori.yaml")
+    cfg["scales"]["t"] = [0.33, 0.0625, 1024]
+    cfg["scale"] = "t"
+    m = DetectionModel(cfg, nc=4)
+    own = m.state_dict()
+    assert set(own) == set(g)
+    m.load_state_dict({k: (own[k] if ("running_" in k or "num_batches" in k) else g[k]) for k in own}, strict=True)
+    m = m.cuda()
+    eps0 = {id(b): (b.eps, b.momentum) for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d)}
+    m.reference_initial_buffers()
+    torch.cuda.synchronize()
+    after = m.state_dict()
+    for k, v in g.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(after[k]) == 2, k
+        elif "running_" in k:
+            close(after[k].cpu(), v, 1e-4, 1e-6, k)
+    assert all((b.eps, b.momentum) == eps0[id(b)] == (1e-3, 0.03) for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))

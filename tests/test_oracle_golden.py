@@ -302,3 +302,31 @@ def test_pre_nms_stage_golden(monkeypatch):
             assert torch.equal(calls[i][0], g[f"{tag}_boxes{i}"]), (tag, i, "boxes handed to nms")
             assert torch.equal(calls[i][1], g[f"{tag}_scores{i}"]), (tag, i, "scores handed to nms")
             assert torch.equal(out[i], g[f"{tag}_out{i}"]), (tag, i, "rows")
+
+
+def test_reference_initial_bn_buffers():
+    """A new reference model does not start from BatchNorm buffers (0, 1): its constructor runs two train-mode forward passes of a
+    zero image with torch's default eps / momentum (tasks.py:284-292).  g10_initbuf.npz holds the parameters and buffers of a
+    freshly constructed reference model; the oracle must reproduce the buffers from the parameters alone."""
+    g = gold("g10_initbuf")
+    cfg = load_yaml("yolov8ori.yaml")
+    cfg["scales"]["t"] = [0.33, 0.0625, 1024]
+    plan, save = om.build_plan(cfg, scale="t", nc=4)
+    shapes = om.param_shapes(plan)
+    assert set(shapes) == set(g), sorted(set(shapes) ^ set(g))[:6]
+    sd = {}
+    for k, v in g.items():
+        if k.endswith("running_mean"):
+            sd[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones_like(v)
+        elif k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(v)
+        else:
+            sd[k] = v.clone()
+    om.reference_initial_buffers(plan, save, sd)
+    for k, v in g.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == 2, k
+        elif "running_" in k:
+            close(sd[k], v, 1e-5, 1e-7, k)
