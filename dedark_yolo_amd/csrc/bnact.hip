@@ -157,10 +157,10 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
                                                                 const float* __restrict__ invstd, int act, int has_bn,
                                                                 double* sums, long pixels, int C, int cgb, int rows) {
   constexpr int VE = DT<T>::VE;
-  extern __shared__ float lds[];               // constants [4][nch], then accumulators [2][nch]
+  extern __shared__ float lds[];               // constants [4][nch], then the per-thread partial sums [2][rows][nch]
   const int tid = threadIdx.x;
   const int nch = cgb * VE, c0 = blockIdx.y * nch;
-  float* sred = lds + 4 * nch;
+  float* part = lds + 4 * nch;
   for (int i = tid; i < nch; i += NT) {
     const int c = c0 + i;
     const bool ok = c < C;
@@ -168,8 +168,6 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
     lds[nch + i] = (shift && ok) ? shift[c] : 0.f;
     lds[2 * nch + i] = (has_bn && ok) ? mean[c] : 0.f;
     lds[3 * nch + i] = (has_bn && ok) ? invstd[c] : 0.f;
-    sred[i] = 0.f;
-    sred[nch + i] = 0.f;
   }
   __syncthreads();
   const Map m = make_map<VE>(C, cgb, rows);
@@ -207,19 +205,27 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
         }
       }
     }
+    // block reduction without atomics (the LDS float atomics serialised up to `rows` deep on every channel and made the order of
+    // the additions, hence the last bits of the sums, depend on wave arrival): each thread parks its VE partial sums, the first
+    // 2 * nch threads then add the `rows` values of one channel in a fixed order
+    float* mine = part + (threadIdx.x / cgb) * nch + m.cl;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      atomicAdd(&sred[m.cl + e], s1[e]);
-      if (has_bn) atomicAdd(&sred[nch + m.cl + e], s2[e]);
+    for (int e = 0; e < VE; e += 4) {
+      *reinterpret_cast<f32x4*>(mine + e) = f32x4{s1[e], s1[e + 1], s1[e + 2], s1[e + 3]};
+      *reinterpret_cast<f32x4*>(mine + rows * nch + e) = f32x4{s2[e], s2[e + 1], s2[e + 2], s2[e + 3]};
     }
   }
   __syncthreads();
   double* dst = sums + (long)(blockIdx.x % DY_BN_BWD_REPLICAS) * 2 * C;
-  for (int i = tid; i < nch; i += NT) {
-    const int c = c0 + i;
-    if (c < C) {
-      atomic_add_f64(dst + c, (double)sred[i]);
-      if (has_bn) atomic_add_f64(dst + C + c, (double)sred[nch + i]);
+  const int CGl = C / VE - blockIdx.y * cgb;                      // channel groups of this block that exist
+  for (int i = tid; i < 2 * nch; i += NT) {
+    const int which = i >= nch, ch = i - which * nch;
+    const int c = c0 + ch;
+    if (c < C && ch / VE < CGl && (which == 0 || has_bn)) {
+      const float* col = part + which * rows * nch + ch;
+      float acc = 0.f;
+      for (int r = 0; r < rows; ++r) acc += col[r * nch];
+      atomic_add_f64(dst + which * C + c, (double)acc);
     }
   }
 }
@@ -395,7 +401,7 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   if (pixels <= 0) return 0;
   const int ve = dtype == DY_F32 ? 4 : 8;
   const Geo g = geometry(pixels, C, ve, 1);
-  size_t shm = 6 * (size_t)g.cgb * ve * sizeof(float);
+  size_t shm = (4 + 2 * (size_t)g.rows) * g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel("bn_act_bwd_reduce_kernel");
   if (dtype == DY_F32)

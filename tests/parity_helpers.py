@@ -104,10 +104,20 @@ def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch
             e = float((g - tgt).norm()) / den if den > 1e-10 else float((g - tgt).norm())
             eo = (float((r - tgt).norm()) / den if den > 1e-10 else float((r - tgt).norm())) if ref64 is not None else 0.0
             errs.append((e, eo, k))
-        # direction of the whole step: cosine between the concatenated gradients
-        dots = [(float((p.grad.detach().double().cpu() * sd[k].grad.double()).sum()), float(p.grad.detach().double().norm()) ** 2,
-                 float(sd[k].grad.double().norm()) ** 2) for k, p in named.items() if p.grad is not None and sd[k].grad is not None]
-        out["grad_cosine"] = sum(d[0] for d in dots) / max((sum(d[1] for d in dots) * sum(d[2] for d in dots)) ** 0.5, 1e-300)
+        # direction of the step: cosine between the concatenated gradients (all tensors / without the front-end, whose gradient has
+        # passed through the whole network AND the image filters) and per tensor
+        trip = {k: (float((p.grad.detach().double().cpu() * sd[k].grad.double()).sum()), float(p.grad.detach().double().norm()) ** 2,
+                    float(sd[k].grad.double().norm()) ** 2) for k, p in named.items() if p.grad is not None and sd[k].grad is not None}
+
+        def cos(keys):
+            d = [trip[k] for k in keys]
+            return sum(t[0] for t in d) / max((sum(t[1] for t in d) * sum(t[2] for t in d)) ** 0.5, 1e-300)
+        out["grad_cosine"] = cos(trip)
+        out["grad_cosine_net"] = cos([k for k in trip if not k.startswith("model.0.")] or list(trip))
+        per = sorted(t[0] / max((t[1] * t[2]) ** 0.5, 1e-300) for t in trip.values())
+        out["grad_cosine_median"] = per[len(per) // 2]
+        out["grad_cosine_p10"] = per[len(per) // 10]
+        out["top_grad_norms"] = sorted(((round(t[2] ** 0.5, 3), k) for k, t in trip.items()), reverse=True)[:4]
         errs.sort(reverse=True)
         out["worst_grad_rel"] = errs[0][0]
         out["worst_grad_key"] = errs[0][2]
