@@ -10,6 +10,7 @@ ModelEMA ultralytics/utils/torch_utils.py:344-377) re-designed around flat HBM-r
   * preprocess_batch's tensor part (uint8 -> /255 -> x^dark_param, recovery mse) is one HIP kernel; the numpy dark-channel
     branch of the reference (train.py:81-97) is dead downstream and reads uninitialised memory: not reproduced.
 """
+import contextlib
 import math
 import os
 from pathlib import Path
@@ -431,11 +432,51 @@ class DetectionTrainer:
         self.pack_plan.repack(self.model)
         return int(ckpt.get("epoch", -1)) + 1
 
-    def train(self, loader, epochs=None):
+    @contextlib.contextmanager
+    def ema_weights(self):
+        """The model on its EMA parameters and buffers, in place (the parameters are views of the flat buffers): what the reference
+        validates and checkpoints (`trainer.ema.ema`, engine/validator.py:104).  Swapped back on exit."""
+        f = self.flat
+        if f.ema is None:
+            yield self.model
+            return
+        keep_p, keep_b = f.p.clone(), f.buf_flat.clone()
+        f.p.copy_(f.ema)
+        f.buf_flat.copy_(f.buf_ema)
+        ops.bump_weights_epoch()
+        try:
+            yield self.model
+        finally:
+            f.p.copy_(keep_p)
+            f.buf_flat.copy_(keep_b)
+            ops.bump_weights_epoch()
+
+    def validate(self, val_loader):
+        """trainer.validate() (engine/trainer.py:471-480): the validator on the EMA weights, forced to fp32 as the fork does
+        (engine/validator.py:105-107 `self.args.half = False`).  Returns (metrics dict, fitness)."""
+        from .validator import DetectionValidator
+        dt = ops.get_compute_dtype()
+        try:
+            with self.ema_weights() as model:
+                metrics = DetectionValidator(self.args)(model, val_loader, dtype=torch.float32)
+        finally:
+            ops.set_compute_dtype(dt)
+            self.model.train()
+        fitness = metrics.get("fitness")
+        if fitness is None:
+            fitness = 0.1 * metrics.get("metrics/mAP50(B)", 0.0) + 0.9 * metrics.get("metrics/mAP50-95(B)", 0.0)
+        return metrics, float(fitness)
+
+    def train(self, loader, epochs=None, val_loader=None, save_dir=None):
+        """The epoch loop of BaseTrainer._do_train (engine/trainer.py:300-400) around train_step: warm-up / accumulation schedule,
+        and at the end of every epoch on rank 0 -- validation on the EMA weights when `val_loader` is given and (args.val or last
+        epoch), fitness / best tracking, last.pt / best.pt when `save_dir` is given and (args.save or last epoch)
+        (:366-380, 408-433).  Returns the per-epoch loss items; self.metrics / self.fitness / self.best_fitness hold the rest."""
         epochs = epochs or self.args.epochs
         nb = len(loader)
         nw = max(round(self.args.warmup_epochs * nb), 100) if self.args.warmup_epochs > 0 else -1
         history = []
+        self.metrics, self.fitness = {}, None
         nbs, bs = float(getattr(self.args, "nbs", 64)), max(int(getattr(self.args, "batch", 64)), 1)
         for epoch in range(epochs):
             for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
@@ -449,4 +490,10 @@ class DetectionTrainer:
                 if step:
                     self.last_opt_step = ni
             history.append([float(v) for v in items])
+            if self.rank in (-1, 0):
+                final_epoch = epoch + 1 == epochs
+                if val_loader is not None and (getattr(self.args, "val", True) or final_epoch):
+                    self.metrics, self.fitness = self.validate(val_loader)
+                if save_dir is not None and (getattr(self.args, "save", True) or final_epoch):
+                    self.save_model(os.path.join(str(save_dir), "weights"), epoch=epoch, fitness=self.fitness)
         return history

@@ -388,3 +388,41 @@ def test_reference_initial_bn_buffers_on_gpu():
         elif "running_" in k:
             close(after[k].cpu(), v, 1e-4, 1e-6, k)
     assert all((b.eps, b.momentum) == eps0[id(b)] == (1e-3, 0.03) for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+
+
+def test_train_loop_validates_on_ema_weights_and_tracks_best(tmp_path):
+    """The epoch contract of BaseTrainer._do_train (engine/trainer.py:366-380, 408-433): after every epoch validate the EMA weights
+    in fp32 (validator.py:105-107), track fitness / best, write last.pt (+ best.pt).  Checked: the metrics are those of the
+    EMA weights (a validator run on a model loaded from the checkpoint's `ema` gives the same numbers), the live parameters are
+    back in place afterwards, the compute dtype is restored, and a worse epoch does not overwrite best.pt."""
+    import bench
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd.engine.model import YOLO
+    from dedark_yolo_amd.engine.validator import DetectionValidator
+    tr = _tiny_trainer("SGD", batch=64, dtype="bf16", warmup_epochs=0.0, epochs=2, imgsz=64, conf=0.001, iou=0.7)
+    try:
+        batches = [bench.synth_batch(90 + i, 4, 64, 20, "cuda") for i in range(3)]
+        for b in batches:
+            b.pop("gamma"), b.pop("n_max", None)
+        vb = bench.synth_batch(99, 4, 64, 20, "cpu")
+        vb.pop("gamma"), vb.pop("n_max", None)
+        vb["ori_shape"] = [(64, 64)] * 4
+        hist = tr.train(batches, epochs=2, val_loader=[vb], save_dir=tmp_path)
+        assert len(hist) == 2 and tr.fitness is not None and set(tr.metrics) >= {"metrics/mAP50(B)", "metrics/mAP50-95(B)", "fitness"}
+        assert dy.get_compute_dtype() == torch.bfloat16 and tr.model.training
+        last, best = tmp_path / "weights" / "last.pt", tmp_path / "weights" / "best.pt"
+        assert last.exists() and best.exists()
+        ck = torch.load(last, map_location="cpu", weights_only=False)
+        assert ck["epoch"] == 1 and ck["best_fitness"] == tr.best_fitness >= tr.fitness
+        # live parameters are not the EMA ones (they moved by SGD steps; the EMA barely moved) and were restored after validation
+        live = tr.flat.p.detach().clone()
+        assert float((live - tr.flat.ema).abs().max()) > 0
+        m2, f2 = tr.validate([vb])
+        assert torch.equal(tr.flat.p, live) and abs(f2 - tr.fitness) <= 1e-6
+        # the same numbers from the checkpoint's EMA weights through the public loader
+        dy.set_compute_dtype(torch.float32)
+        y = YOLO(str(last))
+        got = DetectionValidator(tr.args)(y.model.cuda(), [vb], dtype=torch.float32)
+        assert abs(got["fitness"] - tr.fitness) <= 2e-3, (got["fitness"], tr.fitness)        # checkpoint weights are fp16
+    finally:
+        dy.set_compute_dtype(torch.float32)
