@@ -321,14 +321,14 @@ Geo geometry(long pixels, int C, int ve, int kind /*0 fwd, 1 bwd reduce, 2 bwd a
   const int CG = C / ve;
   g.cgb = CG < NT ? CG : NT;
   g.rows = NT / g.cgb;
-  static const int env_tgt = getenv("DY_BN_BLOCKS") ? atoi(getenv("DY_BN_BLOCKS")) : 0;       // tuning aid
+  static const int env_tgt = dy_env("DY_BN_BLOCKS") ? atoi(dy_env("DY_BN_BLOCKS")) : 0;       // tuning aid
   long target = (1L << 18) / (C > 0 ? C : 1);
   target = target > 2048 ? 2048 : (target < 256 ? 256 : target);
   const long bytes = pixels * C * (ve == 8 ? 2 : 4);
   if (kind != 0 && bytes <= (128L << 20) && target > 512) target = 512;
   // the reduce kernel of a small tensor is all tail (LDS atomics -> 2 device-scope f64 atomics per channel and block):
   // 64ch x 51,200 px 15.9 us with 512 blocks, 12.1 us with 256; 256ch x 12,800 px 16.3 -> 12.4 us
-  static const long small_reduce = getenv("DY_BN_SMALL_REDUCE") ? atol(getenv("DY_BN_SMALL_REDUCE")) : (16L << 20);
+  static const long small_reduce = dy_env("DY_BN_SMALL_REDUCE") ? atol(dy_env("DY_BN_SMALL_REDUCE")) : (16L << 20);
   if (kind == 1 && bytes <= small_reduce && target > 256) target = 256;
   if (env_tgt > 0) target = env_tgt;
   const int gy = dy_cdiv(CG, g.cgb);

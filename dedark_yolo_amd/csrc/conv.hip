@@ -272,12 +272,12 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
-    if (more && !(p.ablate & 1)) {
+    if (more && !(DY_ABLATE_OF(p) & 1)) {
       advance();
       load_step();
     }
-    if (!(p.ablate & 2)) mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
-    if (more && (p.ablate & 8)) continue;
+    if (!(DY_ABLATE_OF(p) & 2)) mma_step<T, TM, TN>(As, Bs, wm * (BM / WM), wn * (BN / WN), lane, acc);
+    if (more && (DY_ABLATE_OF(p) & 8)) continue;
     __syncthreads();
     if (more) {
       store_step();
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
     // bf16: transposed LDS image + ds_read_b64_tr_b16 -> 16-byte stores (conv_epilogue.h); the per-lane 2-byte stores of the
     // scalar path below wrote 64-byte row fragments and made the narrow n-scale layers store-bound
     static_assert(dy_epi::image_bytes<BM, BN>() <= (BM + BN) * ROWB, "epilogue image must fit the staging buffers");
-    if (!(p.ablate & 4))
+    if (!(DY_ABLATE_OF(p) & 4))
       dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act,
                                                  p.accumulate, dst,
                                                  [&](long m) { return dst_offset(p, m); }, csum, csq);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
             float v = dy_act(p.act, a * sc[j] + sf[j]);
             T* o = orow + nn[j];
             if (p.accumulate) v += DT<T>::ld(o);
-            if (!(p.ablate & 4)) DT<T>::st(o, v);
+            if (!(DY_ABLATE_OF(p) & 4)) DT<T>::st(o, v);
           }
         }
       }
@@ -827,7 +827,7 @@ void fill_convp(ConvP& p, const dy_conv_desc* d, const dy_conv_desc* classes, in
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.Ktot = d->KH * d->KW * d->Cs;
-  static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
+  static const int ablate = dy_env("DY_ABLATE") ? atoi(dy_env("DY_ABLATE")) : 0;
   p.ablate = ablate;
   p.dst_row = d->dst_row_stride;
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
@@ -879,7 +879,7 @@ int launch_conv(const dy_conv_desc* d, hipStream_t st, const dy_conv_desc* class
 // (32->32 3x3 at 80x80: 26 -> 34 us) or 1x1 windows (48->32: 34 -> 48 us) -- one round of loads per tap row and the per-block
 // weight staging / epilogue still dominate a 256-pixel block, so those stay on the tiled kernel (`all_shapes` = tests / tuning).
 bool thin_eligible(const dy_conv_desc* d, int mode, bool parity_class = false) {
-  static const bool off = getenv("DY_NO_CONV_THIN") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_THIN") != nullptr;
   static const bool all_shapes = getenv("DY_CONV_THIN_ALL") != nullptr;
   if (off || d->dtype != DY_BF16) return false;
   if (!all_shapes && !parity_class && !(d->Cs == 16 && d->KH * d->KW > 1)) return false;
@@ -954,7 +954,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
   if (dy_dense_dgrad_eligible(d)) return dy_dense_dgrad_launch(d, stream);
   if (dy_conv_small_dgrad_eligible(d)) return dy_conv_small_dgrad_launch(d, stream);
   DY_CHECK(d->dst_planar == nullptr, "dy_conv2d_dgrad: dst_planar is only supported by the direct stem kernel (bf16, 3x3 s2 p1, Cd == 8)");
-  static const bool no_parity = getenv("DY_NO_PARITY_DGRAD") != nullptr;
+  static const bool no_parity = dy_env("DY_NO_PARITY_DGRAD") != nullptr;
   if (d->stride == 2 && d->dil == 1 && !no_parity) {
     // Stride-2 data gradient = 4 independent dense problems, one per parity class (ph, pw) of the output pixel: only the
     // taps kh == (ph + pad) mod 2 reach dx[2*hq + ph], and they read dz[hq + (ph + pad - kh)/2]: a stride-1 correlation over dz
@@ -993,7 +993,7 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
       //  training step 10.4 -> 10.75 ms: the cross-stream waits cost more than the small launches gain)
       // All classes in ONE launch (blocks ordered heaviest class first): four back-to-back launches of 1-, 2-, 2- and 4-tap
       // problems each paid their own launch floor and tail.  DY_PARITY_MULTI=0 keeps the separate launches.
-      static const bool multi = !(getenv("DY_PARITY_MULTI") && atoi(getenv("DY_PARITY_MULTI")) == 0);
+      static const bool multi = !(dy_env("DY_PARITY_MULTI") && atoi(dy_env("DY_PARITY_MULTI")) == 0);
       if (multi && nc > 1) {
         dy_conv_desc r[4];
         bool all_v2 = true, none_v2 = true;
@@ -1054,8 +1054,8 @@ int launch_wgrad(WgP p, float* scratch, long scratch_elems, float* g_oihw, int C
   p.tiles = tiles;
   // enough splits to fill the chip (~8 blocks per CU: swept with tools/wgrad_sweep.py on the n-scale shapes, 2048 blocks beat
   // 1024 by 7 % and 256 lose 55 %), at least 4 steps of pixels per split, and the slabs must fit
-  static const int env_blocks = getenv("DY_WGRAD_BLOCKS") ? atoi(getenv("DY_WGRAD_BLOCKS")) : 0;     // tuning aids
-  static const int env_steps = getenv("DY_WGRAD_STEPS") ? atoi(getenv("DY_WGRAD_STEPS")) : 0;
+  static const int env_blocks = dy_env("DY_WGRAD_BLOCKS") ? atoi(dy_env("DY_WGRAD_BLOCKS")) : 0;     // tuning aids
+  static const int env_steps = dy_env("DY_WGRAD_STEPS") ? atoi(dy_env("DY_WGRAD_STEPS")) : 0;
   const int min_steps = env_steps > 0 ? env_steps : 4;
   long max_splits = (p.M + (long)min_steps * MK - 1) / ((long)min_steps * MK);
   long want = ((env_blocks > 0 ? env_blocks : 2048) + tiles - 1) / tiles;

@@ -171,7 +171,7 @@ static bool thin_eligible(const dy_conv_desc* d) {
 }
 
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d) {
-  static const bool off = getenv("DY_NO_CONV_SMALL") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_SMALL") != nullptr;
   if (off) return false;
   if (thin_eligible(d)) return true;
   return d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1 && d->Cd == 8 &&

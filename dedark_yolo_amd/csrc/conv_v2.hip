@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stamp(p.ablate, 0);
+  stamp(DY_ABLATE_OF(p), 0);
   const int wm = wave >> 1, wn = wave & 1;
   int bid = xcd_remap(blockIdx.x, p.nblk);
   if (pk.ncls > 1) {                       // several problems in one launch: this block's class replaces the launch-wide geometry
@@ -218,23 +218,23 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
     b_key[j] = (row >> 1) & 7;
   }
 
-  stamp(p.ablate, 1);
+  stamp(DY_ABLATE_OF(p), 1);
   issue(0);
   if (NSTAGE > 2 && nsteps > 1) issue(1);
-  stamp(p.ablate, 2);
+  stamp(DY_ABLATE_OF(p), 2);
   for (int s = 0; s < nsteps; ++s) {
-    if (s == 1) stamp(p.ablate, 3);
-    if (s == 9) stamp(p.ablate, 4);
+    if (s == 1) stamp(DY_ABLATE_OF(p), 3);
+    if (s == 9) stamp(DY_ABLATE_OF(p), 4);
     if (NSTAGE > 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + NSTAGE - 1 < nsteps && !(p.ablate & 1)) issue((s + NSTAGE - 1) % NSTAGE);
+    if (s + NSTAGE - 1 < nsteps && !(DY_ABLATE_OF(p) & 1)) issue((s + NSTAGE - 1) % NSTAGE);
     const char* stage = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = 2 * kk + fh;
       u32x4 af[TM], bf[TN];
-      if (p.ablate & 16) {
+      if (DY_ABLATE_OF(p) & 16) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = u32x4{(unsigned)s, 1u, 2u, 3u};
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(stage + b_off[j] + ((c ^ b_key[j]) << 4));
       }
-      if (p.ablate & 2) {
+      if (DY_ABLATE_OF(p) & 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
@@ -260,16 +260,16 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
     }
   }
 
-  stamp(p.ablate, 5);
+  stamp(DY_ABLATE_OF(p), 5);
   // ---- epilogue (conv_epilogue.h): accumulators -> transposed bf16 image in the idle ring -> 16-byte stores through
   // ds_read_b64_tr_b16; csum / csq = per-column sums of the raw accumulators for the BatchNorm statistics below
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
-  if (!(p.ablate & 4))
+  if (!(DY_ABLATE_OF(p) & 4))
     dy_epi::store_tile<BM, BN, WM, WN, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
                                    reinterpret_cast<T*>(p.dst), [&](long m) { return dst_offset(p, m); }, csum, csq);
-  stamp(p.ablate, 6);
-  stamp(p.ablate, 7);
+  stamp(DY_ABLATE_OF(p), 6);
+  stamp(DY_ABLATE_OF(p), 7);
   if (p.stats) {
     __syncthreads();                              // the bf16 image has been consumed: reuse LDS for the column sums
     float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
@@ -357,7 +357,7 @@ bool dy_conv_prefers_256(const dy_conv_desc* d) {
 }
 
 bool dy_conv_v2_eligible(const dy_conv_desc* d) {
-  static const bool off = getenv("DY_NO_CONV_V2") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_V2") != nullptr;
   if (off) return false;
   const long M = (long)d->N * d->Hd * d->Wd;
   if (!((d->dtype == DY_BF16 || d->dtype == DY_F16) && M >= 2048 && (d->src_ld * 2) % 16 == 0)) return false;
@@ -365,7 +365,7 @@ bool dy_conv_v2_eligible(const dy_conv_desc* d) {
   // narrow SOURCE channels (per-lane tap decode, SMALLC).  Measured on the n-scale layers: a win only when the destination is
   // at least one 64-wide tile (96->64 1x1: 50 -> 40 us, 32->64 3x3 s2: 61 -> 54 us); with Cd <= 32 the 256x64 tile is 50-75 %
   // padding and its epilogue-bound blocks lose to the register-staged kernel (32->32 3x3: 31 -> 49 us).  DY_V2_SMALLC=1 forces it.
-  static const bool force = getenv("DY_V2_SMALLC") != nullptr;
+  static const bool force = dy_env("DY_V2_SMALLC") != nullptr;
   return d->Cs % 8 == 0 && d->Cd % 8 == 0 && (d->Cd >= 64 || (force && d->Cd >= 8));
 }
 
@@ -399,7 +399,7 @@ static int v2_launch_impl(const dy_conv_desc* d, int mode, const dy_conv_desc* c
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.Ktot = d->KH * d->KW * d->Cs;
-  static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
+  static const int ablate = dy_env("DY_ABLATE") ? atoi(dy_env("DY_ABLATE")) : 0;
   p.ablate = ablate;
   p.dst_row = d->dst_row_stride;
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
@@ -420,7 +420,7 @@ static int v2_launch_impl(const dy_conv_desc* d, int mode, const dy_conv_desc* c
   // ring -- their barriers and epilogue bursts interleave.  Wide outputs: 128x128 tile on 4 waves, 2 stages = 64 KB (2 blocks /
   // CU; 256->256 3x3 254 -> 239 us, 1280->512 1x1 302 -> 286 us vs 256x128 x 3 stages).  Cd <= 64: 256x64 on 8 waves, 2 stages =
   // 80 KB (64->64 3x3 at 160x160: 433 -> 333 us, also 20 % faster than the band kernel's 64-wide variant).
-  static const int exp_mode = getenv("DY_V2_EXP") ? atoi(getenv("DY_V2_EXP")) : 0;
+  static const int exp_mode = dy_env("DY_V2_EXP") ? atoi(dy_env("DY_V2_EXP")) : 0;
 #define DY_V2_GO(BN_, NS_, BM_) (mode == 0 ? v2::launch<BN_, 0, false, NS_, BM_>(p, st) : v2::launch<BN_, 1, false, NS_, BM_>(p, st))
   if (exp_mode == 1) return wide ? DY_V2_GO(128, 3, 256) : DY_V2_GO(64, 3, 256);        // the first version: one block per CU
   // >= 256 output channels: 256 x 256 tile (one block per CU, 2 stages = 128 KiB).  These kernels stream both operands from L2 /

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stamp(p.ablate, 0);
+  stamp(DY_ABLATE_OF(p), 0);
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, p.nblk);
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- prologue: whole band of chunk 0, weight tiles of steps 0 and 1
-  stamp(p.ablate, 1);
+  stamp(DY_ABLATE_OF(p), 1);
   for (int q = 0; q < p.nslices; ++q) issue_band_slice(Abuf0, q, 0);
   issue_b(0, 0);
   issue_b(0, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  stamp(p.ablate, 2);
+  stamp(DY_ABLATE_OF(p), 2);
 
   // Ping-pong schedule.  Every step has a memory half (issue the DMA of tile +2 / one band slice, read the 16 fragments of
   // this step from LDS, wait for the loads of the previous step) and a matrix half (16 MFMAs), each closed by a barrier.
@@ -182,15 +182,15 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
     char* anext = (c & 1) ? Abuf0 : Abuf1;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      if (c == 0 && t == 1) stamp(p.ablate, 3);
-      if (c == 1 && t == 0) stamp(p.ablate, 4);
+      if (c == 0 && t == 1) stamp(DY_ABLATE_OF(p), 3);
+      if (c == 1 && t == 0) stamp(DY_ABLATE_OF(p), 4);
       // -------- memory half
       bool tile_issued = false, slice_issued = false;
-      if (!(p.ablate & 64)) {
+      if (!(DY_ABLATE_OF(p) & 64)) {
         if (t + 2 < 9) { issue_b(c, t + 2); tile_issued = true; }           // ring slot (t+2)%3: last read in step-1
         else if (more) { issue_b(c + 1, t + 2 - 9); tile_issued = true; }
       }
-      if (more && t < 8 && !(p.ablate & 1)) {
+      if (more && t < 8 && !(DY_ABLATE_OF(p) & 1)) {
         issue_band_slice(anext, t < p.nslices ? t : p.nslices - 1, (c + 1) * BK);
         slice_issued = true;
       }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int cc = 2 * kk + fh;
-        if (p.ablate & 16) {
+        if (DY_ABLATE_OF(p) & 16) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[kk][i] = u32x4{(unsigned)c, 1u, 2u, 3u};
 #pragma unroll
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
       // -------- matrix half
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (p.ablate & 2) {
+        if (DY_ABLATE_OF(p) & 2) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[kk][i]));
 #pragma unroll
@@ -247,16 +247,16 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(P p) {
   }
   if (!late) __builtin_amdgcn_s_barrier();
 
-  stamp(p.ablate, 5);
+  stamp(DY_ABLATE_OF(p), 5);
   // ---- epilogue (conv_epilogue.h): accumulators -> transposed bf16 image in the idle ring -> 16-byte stores through
   // ds_read_b64_tr_b16; csum / csq = per-column sums of the raw accumulators for the BatchNorm statistics below
   const int cl = lane & 31, hh = lane >> 5;
   float csum[TN], csq[TN];
-  if (!(p.ablate & 4))
+  if (!(DY_ABLATE_OF(p) & 4))
     dy_epi::store_tile<BM, BN, 4, 2, TM, TN>(smem, acc, wm, wn, lane, wave, m0, n0, p.M, p.Cd, p.scale, p.shift, p.act, p.accumulate,
                                    reinterpret_cast<T*>(p.dst), [&](long m) { return m * p.dst_ld; }, csum, csq);
-  stamp(p.ablate, 6);
-  stamp(p.ablate, 7);
+  stamp(DY_ABLATE_OF(p), 6);
+  stamp(DY_ABLATE_OF(p), 7);
   if (p.stats) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
@@ -336,7 +336,7 @@ static void v3_fill(const dy_conv_desc* d, v3::P& p) {
   p.L = v3::BM + 2 * (d->Ws + 1);
   p.nslices = (p.L + 64) / 64;      // >= one spare row past L: the always-zero row used for out-of-image taps
   p.a_bytes = p.nslices * 64 * v3::ROW;
-  static const int ablate = getenv("DY_ABLATE") ? atoi(getenv("DY_ABLATE")) : 0;
+  static const int ablate = dy_env("DY_ABLATE") ? atoi(dy_env("DY_ABLATE")) : 0;
   p.ablate = ablate;
 }
 
@@ -348,7 +348,7 @@ extern "C" int dy_debug_conv3_stamps(unsigned long long* out) {
 bool dy_conv_prefers_256(const dy_conv_desc* d);      // conv_v2.hip
 
 bool dy_conv_v3_eligible(const dy_conv_desc* d) {
-  static const bool off = getenv("DY_NO_CONV_V3") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_V3") != nullptr;
   if (off) return false;
   if (!((d->dtype == DY_BF16 || d->dtype == DY_F16) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
   if (d->KHf != 0 || d->dst_row_stride != 0) return false;    // tap subsets / strided destinations: generic kernels only

@@ -440,7 +440,7 @@ static int v4_variant(const dy_conv_desc* d, int mode) {
 static
 #endif
 bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode) {
-  static const bool off = getenv("DY_NO_CONV_V4") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_V4") != nullptr;
   return !off && v4_variant(d, mode) != 0;
 }
 

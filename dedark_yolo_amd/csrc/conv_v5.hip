@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 }  // namespace v5
 
 bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
-  static const bool off = getenv("DY_NO_CONV_V5") != nullptr;
+  static const bool off = dy_env("DY_NO_CONV_V5") != nullptr;
   if (off || (d->dtype != DY_BF16 && d->dtype != DY_F16)) return false;
   if (!(d->Cs % 32 == 0 && d->KH * d->KW <= 25)) return false;
   if (mode == 1 && d->stride != 1) return false;

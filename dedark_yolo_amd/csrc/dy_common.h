@@ -8,6 +8,19 @@
 #define DY_BF16 1
 #define DY_F16 2
 
+// Diagnostics -- kernel ablations (`ablate` bits), s_memtime stamps and dispatch overrides read from the environment -- exist only
+// in `make DIAG=1` builds (-DDY_DIAG): the shipped library compiles them out (the ablate field reads as the constant 0, so the
+// branches and their registers disappear) and its dispatch does not depend on environment variables.  One test hook stays a real
+// getenv: DY_CONV_THIN_ALL (routes every eligible shape to the thin-layer kernel; tests/test_gpu_conv_kernels.py).
+#include <stdlib.h>
+#ifdef DY_DIAG
+#define DY_ABLATE_OF(p) ((p).ablate)
+static inline const char* dy_env(const char* name) { return getenv(name); }
+#else
+#define DY_ABLATE_OF(p) 0
+static inline const char* dy_env(const char*) { return nullptr; }
+#endif
+
 #define DY_ACT_NONE 0
 #define DY_ACT_SILU 1
 #define DY_ACT_LEAKY 2   // LeakyReLU(0.1)

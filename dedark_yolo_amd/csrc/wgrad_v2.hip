@@ -267,12 +267,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 }  // namespace wg2
 
 bool dy_wgrad_v2_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, long x_ld, long dz_ld) {
-  static const bool off = getenv("DY_NO_WGRAD_V2") != nullptr;
+  static const bool off = dy_env("DY_NO_WGRAD_V2") != nullptr;
   if (off) return false;
   const long Ktot = (long)KH * KW * Cin_pad;
   // Cout <= 32 stays on the register-staged kernel (32->32 3x3 at 80x80: 59 us there, 66 us here: 3/4 of the co tile would be
   // padding); DY_WG2_NARROW=<min Cout> overrides for experiments.
-  static const int exp_narrow = getenv("DY_WG2_NARROW") ? atoi(getenv("DY_WG2_NARROW")) : 0;
+  static const int exp_narrow = dy_env("DY_WG2_NARROW") ? atoi(dy_env("DY_WG2_NARROW")) : 0;
   const int min_co = exp_narrow > 0 ? exp_narrow : 64;
   return (dtype == DY_BF16 || dtype == DY_F16) && Cin_pad % 8 == 0 && Cout_pad % 8 == 0 && Cout_pad >= min_co && Ktot >= 64 && M >= 4096 && M < (1L << 31) &&
          (x_ld * 2) % 16 == 0 && (dz_ld * 2) % 16 == 0;
@@ -286,7 +286,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   // flop-per-byte decides: 256 x 256 (128 flop/B, 128 KiB, one block per CU) when the layer has >= 256 output channels
   // (256->256 3x3 at 40x40: 271 -> 200 us = 604 TF; 256->512 3x3 s2: 567 -> 386 us), otherwise 128 x 128 on 4 waves with two
   // co-resident blocks (64 KiB each), which beats 256 x 128 x 3 stages.  DY_WG2_EXP = 1 / 2 / 3 forces 256x128x3 / 256x256 / 128x128.
-  static const int exp_env = getenv("DY_WG2_EXP") ? atoi(getenv("DY_WG2_EXP")) : 0;
+  static const int exp_env = dy_env("DY_WG2_EXP") ? atoi(dy_env("DY_WG2_EXP")) : 0;
   const int exp_mode = exp_env == 3 ? 0 : (exp_env > 0 ? exp_env : (Cout_pad >= 256 ? 2 : 0));
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin_pad;
@@ -319,7 +319,7 @@ int dy_wgrad_v2_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   // about one wave of blocks over the chip (two 128x128 blocks per CU), at least 8 steps per block, and the slabs must fit the
   // scratch buffer.  1,024 blocks were no faster on the YOLOv8-n shapes (sum of 19 layers 913 us vs 908 us) and write + re-read
   // twice the partial tiles (64 KiB per block).
-  static const long env_target = getenv("DY_WG2_TARGET") ? atol(getenv("DY_WG2_TARGET")) : 0;
+  static const long env_target = dy_env("DY_WG2_TARGET") ? atol(dy_env("DY_WG2_TARGET")) : 0;
   const long target = env_target > 0 ? env_target : 512;
   long splits = (target + tiles - 1) / tiles;
   const long max_splits = (p.M + 8L * BKP - 1) / (8L * BKP);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 
 bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
                           long x_ld, long dz_ld, long scratch_elems) {
-  static const bool off = getenv("DY_NO_WGRAD_V3") != nullptr;
+  static const bool off = dy_env("DY_NO_WGRAD_V3") != nullptr;
   if (off) return false;
   if (!((dtype == DY_BF16 || dtype == DY_F16) && (Cin_pad == 64 || Cin_pad == 128) && Cout_pad % 64 == 0 && Cout_pad <= 128 && KH == 3 && KW == 3 && stride == 1 &&
         pad == 1 && dil == 1))
@@ -200,7 +200,7 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
   const int PW = (Wi + 2 + 15) / 16 * 16;
   if (4 * (PW + 8) * Cin_pad * 2 + 2 * PW * wg3::ZPB > 160 * 1024) return false;       // the six row buffers must fit LDS
   // worth it when the pixel loop is long enough to amortise the slab per block (64->64 at 40x40, B = 32 is not)
-  static const long min_m = getenv("DY_WG3_MINM") ? atol(getenv("DY_WG3_MINM")) : 131072;
+  static const long min_m = dy_env("DY_WG3_MINM") ? atol(dy_env("DY_WG3_MINM")) : 131072;
   return (long)N * Hi * Wi >= min_m && scratch_elems >= (long)N * (Cout_pad / wg3::CO) * 9 * Cin_pad * wg3::CO;     // >= 1 block per image
 }
 

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 
 bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, long M, int N, int Hi, int Wi, int Ho, int Wo, long x_ld,
                           long dz_ld, long scratch_elems) {
-  static const bool off = getenv("DY_NO_WGRAD_V4") != nullptr;
+  static const bool off = dy_env("DY_NO_WGRAD_V4") != nullptr;
   if (off || (dtype != DY_BF16 && dtype != DY_F16)) return false;
   if (Cin_pad % 8 != 0 || Cout_pad % 8 != 0 || (x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
   const long Ktot = (long)KH * KW * Cin_pad;
