@@ -75,6 +75,11 @@ _SIGS = {
     "dy_loss_decode": [C.POINTER(DetMaps), vp, vp],
     "dy_tal_assign": [C.POINTER(DetMaps), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "dy_tal_assign_decoded": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "dy_chan_moments": [vp, i64, i32, i64, i32, vp, i32, vp],
+    "dy_sru_fwd": [vp, i64, vp, i64, i32, i64, i32, i32, vp, vp, vp, f32, i32, vp],
+    "dy_sru_bwd": [vp, i64, vp, i64, vp, i64, i32, i64, i32, i32, vp, vp, vp, f32, vp, i32, vp],
+    "dy_cru_fuse_fwd": [vp, i64, vp, i64, i32, i64, i32, vp, i32, vp],
+    "dy_cru_fuse_bwd": [vp, i64, vp, i64, vp, i64, i32, i64, i32, vp, vp, i32, vp],
     "dy_bbox_ciou": [vp, vp, i64, vp, vp, vp],
     "dy_dfl_loss": [vp, vp, i64, vp, vp, vp],
     "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],

@@ -17,7 +17,8 @@ from .. import ops
 from .._C import ACT_LEAKY, ACT_NONE, ACT_SILU, call
 from ..ops import as_nhwc, conv_backward, conv_forward, copy2d, empty_nhwc, ld_of, ptr, stream
 
-__all__ = ("Conv", "Concat", "Bottleneck", "C2f", "SPPF", "Upsample", "AsffTribeLevel", "AsffDoubLevel", "RFBblock", "DFL", "Detect", "AsffDetect",
+__all__ = ("Conv", "Concat", "Bottleneck", "C2f", "SPPF", "Upsample", "AsffTribeLevel", "AsffDoubLevel", "MFRU", "SCConv", "RFBblock", "DFL", "Detect",
+           "AsffDetect",
            "lowlight_recovery", "ExtractParameters2", "autopad")
 
 
@@ -378,6 +379,207 @@ class AsffTribeLevel(DyModule):
             dx2 = dr[2]
             dx1 = conv_backward(tape, ops.upsample_bwd(dr[1], 2))             # compress_level_1
             dx0 = conv_backward(tape, ops.upsample_bwd(dr[0], 4))             # compress_level_0
+        return dx0, dx1, dx2
+
+
+class GroupBatchnorm2d(nn.Module):
+    """Parameter container (reference ultralytics/nn/modules/conv.py:323-343): weight ~ randn(c, 1, 1), bias = 0, eps 1e-10."""
+
+    def __init__(self, c_num, group_num=16, eps=1e-10):
+        super().__init__()
+        assert c_num >= group_num
+        self.group_num = group_num
+        self.weight = nn.Parameter(torch.randn(c_num, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(c_num, 1, 1))
+        self.eps = eps
+
+
+class SRU(nn.Module):
+    """Spatial reconstruction unit (conv.py:346-376): container; the arithmetic is dy_chan_moments + dy_sru_fwd / dy_sru_bwd."""
+
+    def __init__(self, oup_channels, group_num=16, gate_treshold=0.5, torch_gn=False):
+        super().__init__()
+        if torch_gn or gate_treshold != 0.5:
+            raise NotImplementedError("SRU: only the GroupBatchnorm2d variant with the 0.5 gate (what SCConv builds) is implemented")
+        self.gn = GroupBatchnorm2d(oup_channels, group_num=group_num)
+        self.gate_treshold = gate_treshold
+
+
+class CRU(nn.Module):
+    """Channel reconstruction unit (conv.py:379-417): container of its six convolutions (alpha 1/2, squeeze 2, 2 groups, 3x3)."""
+
+    def __init__(self, op_channel, alpha=1 / 2, squeeze_radio=2, group_size=2, group_kernel_size=3):
+        super().__init__()
+        if (alpha, squeeze_radio, group_size, group_kernel_size) != (1 / 2, 2, 2, 3):
+            raise NotImplementedError("CRU: only the default split (what SCConv / MFRU build) is implemented")
+        self.up_channel = up = int(alpha * op_channel)
+        self.low_channel = low = op_channel - up
+        self.squeeze1 = nn.Conv2d(up, up // squeeze_radio, kernel_size=1, bias=False)
+        self.squeeze2 = nn.Conv2d(low, low // squeeze_radio, kernel_size=1, bias=False)
+        self.GWC = nn.Conv2d(up // squeeze_radio, op_channel, kernel_size=group_kernel_size, stride=1, padding=group_kernel_size // 2,
+                             groups=group_size)
+        self.PWC1 = nn.Conv2d(up // squeeze_radio, op_channel, kernel_size=1, bias=False)
+        self.PWC2 = nn.Conv2d(low // squeeze_radio, op_channel - low // squeeze_radio, kernel_size=1, bias=False)
+
+
+class SCConv(DyModule):
+    """Spatial and channel reconstruction convolution (reference conv.py:420-440): SRU then CRU, channels preserved.
+    Every parameter may be used more than once per step (MFRU applies one SCConv to two inputs), so all gradients are collected
+    on the tape (which adds them up) instead of being written in place."""
+
+    def __init__(self, op_channel, group_num=4, gate_treshold=0.5, alpha=1 / 2, squeeze_radio=2, group_size=2, group_kernel_size=3):
+        super().__init__()
+        if op_channel % 64 != 0:
+            raise NotImplementedError("SCConv: channel count must be a multiple of 64 (16-byte channel vectors of the C/8 group slices)")
+        self.SRU = SRU(op_channel, group_num=group_num, gate_treshold=gate_treshold)
+        self.CRU = CRU(op_channel, alpha=alpha, squeeze_radio=squeeze_radio, group_size=group_size, group_kernel_size=group_kernel_size)
+        self.c = op_channel
+
+    def _gwc_views(self):
+        g = self.CRU.GWC
+        key = (g.weight.data_ptr(), g.bias.data_ptr())
+        c = self.__dict__.get("_gwc_cache")
+        if c is None or c[0] != key:
+            h = self.c // 2
+            # slices of the parameters as gradient-taking leaves of their own: conv_backward files their gradients under these
+            # objects, _bwd copies them into the halves of the full GWC gradient
+            c = (key, [g.weight.detach()[j * h:(j + 1) * h].requires_grad_(True) for j in range(2)],
+                 [g.bias.detach()[j * h:(j + 1) * h].requires_grad_(True) for j in range(2)])
+            self.__dict__["_gwc_cache"] = c
+            for w in c[1]:
+                ops.register_pack_view(w)
+        return c[1], c[2]
+
+    def _fwd(self, tape, x):
+        B, C_, H, W = x.shape
+        if C_ != self.c:
+            raise RuntimeError(f"SCConv: expected {self.c} channels, got {C_}")
+        dt, dev, did, st = x.dtype, x.device, ops.dt_id(x.dtype), stream()
+        gn, cru = self.SRU.gn, self.CRU
+        mom = torch.zeros((B, C_, 2), dtype=torch.float64, device=dev)
+        call("dy_chan_moments", ptr(x), ld_of(x), B, H * W, C_, ptr(mom), did, st)
+        y = empty_nhwc(B, C_, H, W, dt, dev)
+        call("dy_sru_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), B, H * W, C_, gn.group_num, ptr(mom), ptr(gn.weight), ptr(gn.bias),
+             float(gn.eps), did, st)
+        h, q, e = C_ // 2, C_ // 4, C_ // 8
+        buf = empty_nhwc(B, 2 * C_, H, W, dt, dev)                       # cat(Y1 [C], PWC2(low) [3C/4], low [C/4])
+        kw = dict(shared=True)
+        sq1 = conv_forward(tape, y[:, :h], cru.squeeze1.weight, None, None, ACT_NONE, 1, 0, 1, False, **kw)
+        sq2 = conv_forward(tape, y[:, h:], cru.squeeze2.weight, None, None, ACT_NONE, 1, 0, 1, False, out=buf[:, 2 * C_ - q:], **kw)
+        wv, bv = self._gwc_views()
+        for j in range(2):                                               # grouped 3x3: group j maps channels [j e, (j+1) e) to [j h, (j+1) h)
+            conv_forward(tape, sq1[:, j * e:(j + 1) * e], wv[j], bv[j], None, ACT_NONE, 1, 1, 1, False, out=buf[:, j * h:(j + 1) * h], **kw)
+        pw1 = conv_forward(tape, sq1, cru.PWC1.weight, None, None, ACT_NONE, 1, 0, 1, False, **kw)
+        copy2d(pw1, buf[:, :C_], accumulate=True)                        # Y1 = GWC(up) + PWC1(up)
+        conv_forward(tape, sq2, cru.PWC2.weight, None, None, ACT_NONE, 1, 0, 1, False, out=buf[:, C_:2 * C_ - q], **kw)
+        mom2 = torch.zeros((B, 2 * C_, 2), dtype=torch.float64, device=dev)
+        call("dy_chan_moments", ptr(buf), ld_of(buf), B, H * W, 2 * C_, ptr(mom2), did, st)
+        res = empty_nhwc(B, C_, H, W, dt, dev)
+        call("dy_cru_fuse_fwd", ptr(buf), ld_of(buf), ptr(res), ld_of(res), B, H * W, C_, ptr(mom2), did, st)
+        if tape is not None:
+            tape.push(dict(x=x, mom=mom, buf=buf, mom2=mom2, views=(wv, bv)))
+        return res
+
+    def _bwd(self, tape, dres, needs=(True,)):
+        s = tape.pop()
+        x, mom, buf, mom2, (wv, bv) = s["x"], s["mom"], s["buf"], s["mom2"], s["views"]
+        B, C_, H, W = x.shape
+        dt, dev, did, st = x.dtype, x.device, ops.dt_id(x.dtype), stream()
+        gn, cru = self.SRU.gn, self.CRU
+        h, q, e = C_ // 2, C_ // 4, C_ // 8
+        dbuf = empty_nhwc(B, 2 * C_, H, W, dt, dev)
+        ds = torch.zeros((B, 2 * C_, 2), dtype=torch.float64, device=dev)
+        call("dy_cru_fuse_bwd", ptr(buf), ld_of(buf), ptr(dres), ld_of(dres), ptr(dbuf), ld_of(dbuf), B, H * W, C_, ptr(mom2), ptr(ds), did, st)
+        conv_backward(tape, dbuf[:, C_:2 * C_ - q], dx_out=dbuf[:, 2 * C_ - q:], accumulate=True)       # PWC2: d low' += ...
+        dsq1 = conv_backward(tape, dbuf[:, :C_])                                                       # PWC1
+        gw = torch.empty_like(cru.GWC.weight)
+        gb = torch.empty_like(cru.GWC.bias)
+        for j in (1, 0):                                                                               # GWC groups, reverse order
+            conv_backward(tape, dbuf[:, j * h:(j + 1) * h], dx_out=dsq1[:, j * e:(j + 1) * e], accumulate=True)
+            gw[j * h:(j + 1) * h].copy_(tape.pgrads.pop(wv[j]).view(h, e, 3, 3))
+            gb[j * h:(j + 1) * h].copy_(tape.pgrads.pop(bv[j]).view(h))
+        ops._add_pgrad(tape, cru.GWC.weight, gw)
+        ops._add_pgrad(tape, cru.GWC.bias, gb)
+        dy = empty_nhwc(B, C_, H, W, dt, dev)
+        conv_backward(tape, dbuf[:, 2 * C_ - q:], dx_out=dy[:, h:])                                    # squeeze2
+        conv_backward(tape, dsq1, dx_out=dy[:, :h])                                                    # squeeze1
+        dx = empty_nhwc(B, C_, H, W, dt, dev)
+        red = torch.zeros((B, C_, 2), dtype=torch.float64, device=dev)
+        call("dy_sru_bwd", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dx), ld_of(dx), B, H * W, C_, gn.group_num, ptr(mom), ptr(gn.weight),
+             ptr(gn.bias), float(gn.eps), ptr(red), did, st)
+        tot = red.sum(0).float()
+        ops._add_pgrad(tape, gn.weight, tot[:, 1].reshape(C_, 1, 1))
+        ops._add_pgrad(tape, gn.bias, tot[:, 0].reshape(C_, 1, 1))
+        return dx
+
+
+def _flush_shared_grads(tape):
+    """Gradients collected on the tape for parameters that a module uses more than once: under the trainer's direct placement they
+    are copied into the parameter's slot of the flat gradient buffer (and leave the tape), otherwise autograd gets them."""
+    for p in list(tape.pgrads):
+        gd = ops._grad_dst(p)
+        if gd is not None:
+            gd.copy_(tape.pgrads.pop(p).view_as(gd))
+
+
+class MFRU(DyModule):
+    """Multi-scale feature reconstruction unit (reference block.py:164-217, yolov8-3.yaml).  Inputs (P5 512 ch, P4 512 ch, P3 256 ch);
+    ONE SCConv(512) + 1x1 conv serve both coarse levels and ONE SCConv(256) serves the fine level and the fused map; output 256
+    channels at the P3 size."""
+
+    def __init__(self, level=None):
+        super().__init__()
+        compress_c = 16
+        self.scconv512 = SCConv(512)
+        self.scconv256 = SCConv(256)
+        self.pwconv = nn.Conv2d(512, 256, 1, 1, 0)
+        self.weight_level_0 = nn.Conv2d(256, compress_c, 1, 1, 0)
+        self.weight_level_1 = nn.Conv2d(256, compress_c, 1, 1, 0)
+        self.weight_level_2 = nn.Conv2d(256, compress_c, 1, 1, 0)
+        self.weight_levels = nn.Conv2d(compress_c * 3, 3, 1, 1, 0)
+
+    def _pw(self, tape, m, x, out=None):
+        return conv_forward(tape, x, m.weight, m.bias, None, ACT_NONE, 1, 0, 1, False, out=out, shared=True)
+
+    def _fwd(self, tape, x0, x1, x2):
+        r0 = ops.upsample_fwd(self._pw(tape, self.pwconv, self.scconv512._fwd(tape, x0)), 4)
+        r1 = ops.upsample_fwd(self._pw(tape, self.pwconv, self.scconv512._fwd(tape, x1)), 2)
+        r2 = self.scconv256._fwd(tape, x2)
+        B, Cc, H, W = r2.shape
+        if tuple(r0.shape) != tuple(r2.shape) or tuple(r1.shape) != tuple(r2.shape):
+            raise RuntimeError("MFRU: inputs must be at strides 4 : 2 : 1")
+        wv = empty_nhwc(B, 48, H, W, r2.dtype, r2.device)
+        self._pw(tape, self.weight_level_0, r0, out=wv[:, 0:16])
+        self._pw(tape, self.weight_level_1, r1, out=wv[:, 16:32])
+        self._pw(tape, self.weight_level_2, r2, out=wv[:, 32:48])
+        logits = self._pw(tape, self.weight_levels, wv)
+        fused = empty_nhwc(B, Cc, H, W, r2.dtype, r2.device)
+        call("dy_asff_fuse_fwd", ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), ptr(r2), ld_of(r2), ptr(logits), ld_of(logits),
+             ptr(fused), ld_of(fused), B * H * W, Cc, ops.dt_id(r2.dtype), stream())
+        if tape is not None:
+            tape.push(dict(r0=r0, r1=r1, r2=r2, logits=logits))
+        return self.scconv256._fwd(tape, fused)
+
+    def _bwd(self, tape, dy, needs=(True, True, True)):
+        dfused = self.scconv256._bwd(tape, dy)
+        s = tape.pop()
+        r0, r1, r2, logits = s["r0"], s["r1"], s["r2"], s["logits"]
+        B, Cc, H, W = r2.shape
+        dt, dev = r2.dtype, r2.device
+        dr = [empty_nhwc(B, Cc, H, W, dt, dev) for _ in range(3)]
+        lw = ld_of(logits)
+        dlog = empty_nhwc(B, lw, H, W, dt, dev)
+        call("dy_asff_fuse_bwd", ptr(dfused), ld_of(dfused), ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), ptr(r2), ld_of(r2),
+             ptr(logits), lw, ptr(dr[0]), ld_of(dr[0]), ptr(dr[1]), ld_of(dr[1]), ptr(dr[2]), ld_of(dr[2]), ptr(dlog), lw,
+             B * H * W, Cc, 0, 0, 0, ops.dt_id(dt), stream())
+        dwv = conv_backward(tape, dlog[:, :3])                                # weight_levels -> [B,48,H,W]
+        conv_backward(tape, dwv[:, 32:48], dx_out=dr[2], accumulate=True)
+        conv_backward(tape, dwv[:, 16:32], dx_out=dr[1], accumulate=True)
+        conv_backward(tape, dwv[:, 0:16], dx_out=dr[0], accumulate=True)
+        dx2 = self.scconv256._bwd(tape, dr[2])
+        dx1 = self.scconv512._bwd(tape, conv_backward(tape, ops.upsample_bwd(dr[1], 2)))
+        dx0 = self.scconv512._bwd(tape, conv_backward(tape, ops.upsample_bwd(dr[0], 4)))
+        _flush_shared_grads(tape)
         return dx0, dx1, dx2
 
 

@@ -14,12 +14,13 @@ import torch.nn as nn
 import yaml
 
 from .. import ops
-from .modules import (AsffDetect, AsffDoubLevel, AsffTribeLevel, C2f, Concat, Conv, Detect, RFBblock, SPPF, Upsample, lowlight_recovery)
+from .modules import (AsffDetect, AsffDoubLevel, AsffTribeLevel, C2f, Concat, Conv, Detect, MFRU, RFBblock, SPPF, Upsample,
+                      lowlight_recovery)
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg" / "models" / "v8"
 
 _REGISTRY = dict(Conv=Conv, C2f=C2f, SPPF=SPPF, Concat=Concat, Detect=Detect, AsffDetect=AsffDetect, AsffTribeLevel=AsffTribeLevel,
-                 AsffDoubLevel=AsffDoubLevel, RFBblock=RFBblock, lowlight_recovery=lowlight_recovery)
+                 AsffDoubLevel=AsffDoubLevel, MFRU=MFRU, RFBblock=RFBblock, lowlight_recovery=lowlight_recovery)
 _REGISTRY["nn.Upsample"] = Upsample
 
 
@@ -80,6 +81,7 @@ _RULES = {
     lowlight_recovery: lambda r: (r.args, r.args[0], r.repeats),
     AsffTribeLevel: lambda r: (r.args, 512 if r.args[0] in (0, 1) else 256, r.repeats),       # tasks.py:892-896
     AsffDoubLevel: lambda r: (r.args, 512 if r.args[0] == 0 else 256, r.repeats),
+    MFRU: lambda r: (r.args, 256, r.repeats),                                                  # tasks.py:890-891
     Detect: lambda r: ([*r.args, list(r.ch_in)], r.ch_in[0], r.repeats),
     AsffDetect: lambda r: ([*r.args, list(r.ch_in)], r.ch_in[0], r.repeats),
 }
@@ -331,6 +333,8 @@ class DetectionModel(BaseModel):
                 s.append(s[L.i - 1] if f[0] == -1 else s[f[0]])
             elif isinstance(L, (AsffTribeLevel, AsffDoubLevel)):
                 s.append(s[f[L.level]])
+            elif isinstance(L, MFRU):
+                s.append(s[f[2]])                      # fuses at the finest of its three inputs
             elif isinstance(L, Detect):
                 return [float(s[j]) for j in f]
             else:

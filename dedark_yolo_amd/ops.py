@@ -322,7 +322,7 @@ def bn_fold_is_current(bn):
 
 class ConvCtx:
     __slots__ = ("x", "z", "aff", "weight", "bias", "bn", "act", "k", "stride", "pad", "dil", "cout", "cout_pad", "cin_pad",
-                 "has_bn", "y", "owner")
+                 "has_bn", "y", "owner", "shared")
 
 
 def _conv_desc(src, w, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, KH, KW, stride, pad, dil, scale, shift, act, stats, accumulate, dtype):
@@ -347,7 +347,7 @@ def flush_bn_counters():
 
 
 def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pad=0, dil=1, training=False, out=None,
-                 residual=None, owner=None):
+                 residual=None, owner=None, shared=False):
     """y = act(bn(conv(x) [+ bias])) [+ residual].  x: NHWC view; returns an NHWC view (into `out` when given).
 
     Training + bn: conv kernel (raw z + batch statistics) -> finalize -> fused affine/activation/residual pass.
@@ -373,6 +373,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         ctx = ConvCtx()
         ctx.x, ctx.weight, ctx.bias, ctx.bn, ctx.act = x, weight, bias, bn, act
         ctx.owner = owner if owner is not None else weight
+        ctx.shared = shared        # parameters used more than once per step (MFRU): gradients go through tape.pgrads, which adds them up
         ctx.k, ctx.stride, ctx.pad, ctx.dil = (KH, KW), stride, pad, dil
         ctx.cout, ctx.cout_pad, ctx.cin_pad, ctx.has_bn = Cout, cout_pad, cin_pad, has_bn
     if batch_stats:
@@ -570,6 +571,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     pixels = B * Ho * Wo
     did = dt_id(dtype)
     st = stream()
+    _grad_dst = (lambda p: None) if getattr(ctx, "shared", False) else globals()["_grad_dst"]
     if ctx.has_bn:
         aff, z, bn = ctx.aff, ctx.z, ctx.bn
         sums = arena.alloc(2 * cout_pad * _C.BN_BWD_REPLICAS, dev)

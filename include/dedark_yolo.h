@@ -213,6 +213,26 @@ int dy_tal_assign_decoded(const float* pd_scores, const float* pd_bboxes, const 
                           const int32_t* counts, int B, int A, int nc, int n_max, float* work_f, int32_t* work_i, uint8_t* work_b,
                           int32_t* target_gt_idx, uint8_t* fg_mask, float* norm, int32_t* target_label, float* target_box,
                           void* stream);
+/* ---- SCConv pieces of MFRU (reference ultralytics/nn/modules/conv.py:323-440, block.py:164-217); NHWC views, HW = pixels per image ----
+ * dy_chan_moments: out[n][c][2] += (sum x, sum x^2) over the pixels of image n (out zeroed by the caller): the group statistics
+ * of GroupBatchnorm2d (conv.py:337-343) and the AdaptiveAvgPool2d(1) of CRU (conv.py:403,415). */
+int dy_chan_moments(const void* x, int64_t ld, int N, int64_t HW, int C, double* out, int dtype, void* stream);
+/* SRU.forward (conv.py:360-378): group norm over `groups` channel groups per image (torch.std: unbiased; eps added to std),
+ * gate sigmoid(gn * gamma / sum(gamma)) >= 0.5, cross reconstruction y[c] = m[c] gn[c] + (1 - m[c']) gn[c'], c' = c +- C/2.
+ * moments = dy_chan_moments(x). */
+int dy_sru_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int64_t HW, int C, int groups, const double* moments,
+               const float* gamma, const float* beta, float eps, int dtype, void* stream);
+/* its backward: dx (written), red[n][c][2] += (sum dgn, sum dgn * xhat) (zeroed by the caller) from which the caller takes
+ * d gamma[c] = sum_n red[n][c][1], d beta[c] = sum_n red[n][c][0] (the gate has no gradient). */
+int dy_sru_bwd(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int N, int64_t HW, int C, int groups,
+               const double* moments, const float* gamma, const float* beta, float eps, double* red, int dtype, void* stream);
+/* CRU tail (conv.py:413-417): o [.., 2C] = cat(Y1, Y2); s = softmax over the 2C channels of mean_pixels(o) per image;
+ * res[c] = o[c] s[c] + o[c + C] s[c + C].  moments = dy_chan_moments(o) with 2C channels. */
+int dy_cru_fuse_fwd(const void* o, int64_t o_ld, void* res, int64_t r_ld, int N, int64_t HW, int C, const double* moments, int dtype,
+                    void* stream);
+/* its backward: dout [.., 2C] (written); ds[n][k][2] scratch (zeroed by the caller; slot 0 = sum_pixels dres[c(k)] o[k]). */
+int dy_cru_fuse_bwd(const void* o, int64_t o_ld, const void* dres, int64_t d_ld, void* dout, int64_t do_ld, int N, int64_t HW, int C,
+                    const double* moments, double* ds, int dtype, void* stream);
 /* CIoU of n box pairs, xyxy f32 (reference ultralytics/utils/metrics.py:75-128 bbox_iou(b1, b2, xywh=False, CIoU=True): eps added to
  * h only, alpha constant in the backward); grad_b1 (nullable) [n,4] = d out[i] / d b1[i]. */
 int dy_bbox_ciou(const float* b1, const float* b2, int64_t n, float* out, float* grad_b1, void* stream);

@@ -66,6 +66,8 @@ def build_plan(cfg, scale=None, nc=None, ch=3):
         elif kind == "RFBblock":
             c2 = cin
             spec.update(c1=args[0])
+        elif kind == "MFRU":
+            c2 = 256                                  # tasks.py:890-891
         elif kind == "Detect":
             c2 = None
             spec.update(nc=args[0], ch=cin)
@@ -77,6 +79,18 @@ def build_plan(cfg, scale=None, nc=None, ch=3):
             chans = []
         chans.append(c2)
     return plan, sorted(set(save))
+
+
+def scconv_shapes(out, p, c):
+    """state_dict entries of SCConv(c) (conv.py:420-440; GroupBatchnorm2d :323-335, CRU :379-404)."""
+    out[p + "SRU.gn.weight"] = (c, 1, 1)
+    out[p + "SRU.gn.bias"] = (c, 1, 1)
+    out[p + "CRU.squeeze1.weight"] = (c // 4, c // 2, 1, 1)
+    out[p + "CRU.squeeze2.weight"] = (c // 4, c // 2, 1, 1)
+    out[p + "CRU.GWC.weight"] = (c, c // 8, 3, 3)
+    out[p + "CRU.GWC.bias"] = (c,)
+    out[p + "CRU.PWC1.weight"] = (c, c // 4, 1, 1)
+    out[p + "CRU.PWC2.weight"] = (c - c // 4, c // 4, 1, 1)
 
 
 def detect_widths(nc, ch):
@@ -144,6 +158,15 @@ def param_shapes(plan):
             for j in range(3):
                 addconv(p + f"weight_level_{j}.", d, 8, 1)
             plain(p + "weight_levels.", 24, 3, 1)
+        elif kind == "MFRU":
+            scconv_shapes(out, p + "scconv512.", 512)
+            scconv_shapes(out, p + "scconv256.", 256)
+            plain(p + "pwconv.", 512, 256, 1)
+            for j in range(3):
+                plain(p + f"weight_level_{j}.", 256, 16, 1)
+            plain(p + "weight_levels.", 48, 3, 1)
+        elif kind == "SCConv":
+            scconv_shapes(out, p, L["c"])
         elif kind == "AsffDoubLevel":
             lv = L["level"]
             d = (512, 256)[lv]
@@ -304,6 +327,43 @@ def asff2(sd, p, xs, level, train):
     return conv_bn_leaky(sd, p + "expand.", fused, 3, 1, train)
 
 
+def scconv(sd, p, x, groups=4):
+    """SCConv.forward (conv.py:420-440): SRU (:346-376 with GroupBatchnorm2d :323-343) then CRU (:379-417).
+    SRU: normalise each of `groups` channel groups of every image by its mean and UNBIASED std (+1e-10 outside the root), affine;
+    channels whose sigmoid(gn * gamma / sum(gamma)) reaches 0.5 are "informative"; the output adds every informative value to the
+    non-informative value of the channel half a tensor away.  CRU: halves squeezed 2x by 1x1 convs; upper = grouped 3x3 (2 groups,
+    bias) + 1x1 to C channels; lower = cat(1x1 to 3C/4, itself); the 2C channels are scaled by a softmax over their global means
+    and the two halves added."""
+    N, C, H, W = x.shape
+    gw, gb = sd[p + "SRU.gn.weight"], sd[p + "SRU.gn.bias"]
+    t = x.reshape(N, groups, -1)
+    t = (t - t.mean(2, keepdim=True)) / (t.std(2, keepdim=True) + 1e-10)
+    gn = t.reshape(N, C, H, W) * gw + gb
+    informative = torch.sigmoid(gn * (gw / gw.sum()).view(1, C, 1, 1)) >= 0.5
+    keep, rest = gn * informative, gn * ~informative
+    h = C // 2
+    y = torch.cat((keep[:, :h] + rest[:, h:], keep[:, h:] + rest[:, :h]), 1)
+    up = F.conv2d(y[:, :h], sd[p + "CRU.squeeze1.weight"])
+    low = F.conv2d(y[:, h:], sd[p + "CRU.squeeze2.weight"])
+    y1 = F.conv2d(up, sd[p + "CRU.GWC.weight"], sd[p + "CRU.GWC.bias"], 1, 1, 1, 2) + F.conv2d(up, sd[p + "CRU.PWC1.weight"])
+    o = torch.cat((y1, F.conv2d(low, sd[p + "CRU.PWC2.weight"]), low), 1)
+    o = F.softmax(o.mean((2, 3), keepdim=True), dim=1) * o
+    return o[:, :C] + o[:, C:]
+
+
+def mfru(sd, p, xs):
+    """MFRU.forward (block.py:188-217). xs = (P5 512 ch, P4 512 ch, P3 256 ch); the same scconv512 + pwconv serve P5 and P4, the same
+    scconv256 serves P3 and the fused map."""
+    x0, x1, x2 = xs
+    pw = lambda t: F.conv2d(t, sd[p + "pwconv.weight"], sd[p + "pwconv.bias"])
+    r0 = F.interpolate(pw(scconv(sd, p + "scconv512.", x0)), scale_factor=4, mode="nearest")
+    r1 = F.interpolate(pw(scconv(sd, p + "scconv512.", x1)), scale_factor=2, mode="nearest")
+    r2 = scconv(sd, p + "scconv256.", x2)
+    w = torch.cat([F.conv2d(r, sd[p + f"weight_level_{j}.weight"], sd[p + f"weight_level_{j}.bias"]) for j, r in enumerate((r0, r1, r2))], 1)
+    w = F.softmax(F.conv2d(w, sd[p + "weight_levels.weight"], sd[p + "weight_levels.bias"]), dim=1)
+    return scconv(sd, p + "scconv256.", r0 * w[:, 0:1] + r1 * w[:, 1:2] + r2 * w[:, 2:])
+
+
 def rfb(sd, p, x):
     """RFBblock.forward (block.py:703-734): 4 branches of biased convs (no BN/act), dilations 1/1/2/3, cat."""
     def cv(name, t, k, pad, dil=1):
@@ -407,6 +467,8 @@ def forward(plan, save, sd, x, train, A=None, IcA=None, want_front=False):
             x = asff(sd, p, x, L["level"], train)
         elif kind == "RFBblock":
             x = rfb(sd, p, x)
+        elif kind == "MFRU":
+            x = mfru(sd, p, x)
         elif kind == "Detect":
             # strides as the reference's 256x256 probe would find them (tasks.py:284-292): input H / map H
             strides = [float(in_h // t.shape[2]) for t in x]

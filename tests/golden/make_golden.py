@@ -388,6 +388,19 @@ def g_variants():
     with torch.no_grad():
         y, maps = det2([t.clone() for t in x])
     save("g2_asffdetect_eval", seed=240, x0=x[0], x1=x[1], x2=x[2], y=y, m0=maps[0], m1=maps[1], m2=maps[2])
+    # SCConv (conv.py:420-440) alone and MFRU (block.py:164-217), whose two SCConvs / pwconv are each applied twice
+    from ultralytics.nn.modules.block import MFRU
+    from ultralytics.nn.modules.conv import SCConv
+    run_block("g2_scconv", SCConv(64), [rnd(36, 2, 64, 7, 9, lo=-1, hi=1)], 250)
+    mfru_in = [rnd(37, 2, 512, 2, 3, lo=-1, hi=1), rnd(38, 2, 512, 4, 6, lo=-1, hi=1), rnd(39, 2, 256, 8, 12, lo=-1, hi=1)]
+    run_block("g2_mfru", MFRU(None), mfru_in, 251, listin=True)
+    # the whole yolov8-3.yaml graph at scale l: key set and parameter count of the reference model (names only, no weights)
+    d = yaml_model_load("yolov8-3.yaml")
+    d["scale"] = "l"
+    m = DetectionModel(d, ch=3, nc=20, verbose=False)
+    keys = sorted(m.state_dict().keys())
+    save("g2_yolov8_3_keys", n_params=sum(p.numel() for p in m.parameters()), keys=np.array(keys),
+         shapes=np.array([str(tuple(m.state_dict()[k].shape)) for k in keys]))
 
 
 # ------------------------------------------------------------------ G7: a checkpoint exactly as the reference trainer writes it

@@ -87,18 +87,19 @@ def _blocks():
         "g2_asff0": (lambda: M.AsffTribeLevel(0), 3, True), "g2_asff1": (lambda: M.AsffTribeLevel(1), 3, True),
         "g2_asff2": (lambda: M.AsffTribeLevel(2), 3, True), "g2_asff2_0": (lambda: M.AsffDoubLevel(0), 2, True),
         "g2_detect_train": (detect, 3, True), "g2_asffdetect_train": (asffdetect, 3, True),
+        "g2_scconv": (lambda: M.SCConv(64), 1, False), "g2_mfru": (lambda: M.MFRU(None), 3, True),
     }
 
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["g2_conv_s2", "g2_conv_1x1", "g2_c2f_sc", "g2_c2f_nosc", "g2_sppf", "g2_rfb", "g2_asff0", "g2_asff1",
-                                  "g2_asff2", "g2_asff2_0", "g2_detect_train", "g2_asffdetect_train"])
+                                  "g2_asff2", "g2_asff2_0", "g2_detect_train", "g2_asffdetect_train", "g2_scconv", "g2_mfru"])
 def test_block_goldens_low_precision(name, dtype):
     _supported(dtype)
     make, nin, listin = _blocks()[name]
     e_y, e_dx, e_dp = _block(name, make(), dtype, nin, listin)
     print(f"{name} {dtype}: forward {e_y:.2e}  dx {e_dx:.2e}  dparam {e_dp:.2e}")
-    ill = "sppf" in name or "asff" in name and "detect" not in name
+    ill = "sppf" in name or ("asff" in name and "detect" not in name) or "scconv" in name or "mfru" in name      # + hard gates of SRU
     b_y, b_g = (2e-2, 0.30 if ill else 3e-2) if dtype == torch.bfloat16 else (3e-3, 0.15 if ill else 6e-3)
     assert e_y <= b_y and e_dx <= b_g and e_dp <= b_g, (e_y, e_dx, e_dp)
 

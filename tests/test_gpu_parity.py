@@ -92,6 +92,59 @@ def test_asff_two_level_golden(level):
     _run_block(f"g2_asff2_{level}", AsffDoubLevel(level), nin=2, listin=True)
 
 
+def test_scconv_golden():
+    """SCConv (reference conv.py:420-440): group norm with unbiased std, gate, cross reconstruction, grouped 3x3, pooled softmax."""
+    from dedark_yolo_amd.nn.modules import SCConv
+    _run_block("g2_scconv", SCConv(64))
+
+
+def test_mfru_golden():
+    """MFRU (reference block.py:164-217): scconv512 + pwconv applied to P5 and P4, scconv256 to P3 and to the fused map -- the
+    parameter gradients are sums over both uses."""
+    from dedark_yolo_amd.nn.modules import MFRU
+    _run_block("g2_mfru", MFRU(None), nin=3, listin=True)
+
+
+def test_yolov8_3_graph_vs_oracle_and_direct_gradient_placement():
+    """cfg/models/v8/yolov8-3.yaml at scale l (MFRU + RFB + ASFF): one training step against the oracle, then the same step under
+    the trainer -- whose kernels write gradients straight into the flat buffer, except for MFRU's shared parameters, which are
+    summed on the tape and copied in -- must leave the same gradients."""
+    from dedark_yolo_amd.engine.trainer import DetectionTrainer, get_cfg
+    from parity_helpers import build_models, make_batch, model_parity_case
+    r = model_parity_case("yolov8-3.yaml", "l", None, 77, 128, 2, [2, 3])
+    print("yolov8-3", {k: r[k] for k in ("loss", "oracle_loss", "median_grad_rel", "worst5")})
+    assert abs(r["loss"] - r["oracle_loss"]) <= 1e-4 * abs(r["oracle_loss"])
+    assert r["grad_finite"] and r["n_nograd"] == 0 and r["median_grad_rel"] < 1e-2
+    model, _ = build_models("yolov8-3.yaml", "l", None, 77)
+    batch = make_batch(78, 2, 128, [2, 3])
+    gb = dict(batch)
+    gb["img"] = batch["img"].pow(3.0).cuda()
+    gb["recovery_loss_batch"] = torch.tensor(0.0123, device="cuda")
+    model.train()
+    loss, _ = model(dict(gb))
+    loss.backward()
+    torch.cuda.synchronize()
+    want = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    model2, _ = build_models("yolov8-3.yaml", "l", None, 77)
+    tr = DetectionTrainer(get_cfg(dict(model="yolov8-3", dtype="fp32", optimizer="SGD", batch=64)))
+    tr.setup(model2)
+    loss2, _ = tr.model(dict(gb))
+    loss2.backward()
+    from dedark_yolo_amd import ops
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    assert abs(float(loss2) - float(loss)) <= 1e-5 * abs(float(loss))
+    worst = 0.0
+    for k, p in tr.model.named_parameters():
+        if k in want:
+            den = float(want[k].norm())
+            e = float((p.grad - want[k]).norm()) / den if den > 1e-8 else float((p.grad - want[k]).norm())
+            worst = max(worst, e)
+            if "scconv" in k or "pwconv" in k:
+                assert e <= 1e-3, (k, e)
+    assert worst <= 5e-2, worst
+
+
 def test_asff_detect_goldens():
     from dedark_yolo_amd.nn.modules import AsffDetect
     from parity_helpers import load_sd, set_bn

@@ -112,6 +112,24 @@ def test_asff_two_level_golden(level):
     _block(f"g2_asff2_{level}", lambda sd, x: om.asff2(sd, "", x, level, True), _shapes(dict(kind="AsffDoubLevel", level=level)), nin=2)
 
 
+def test_scconv_and_mfru_goldens():
+    """SCConv (conv.py:420-440) alone, and MFRU (block.py:164-217) whose SCConvs / pwconv are applied twice each (shared weights)."""
+    _block("g2_scconv", lambda sd, x: om.scconv(sd, "", x[0]), _shapes(dict(kind="SCConv", c=64)))
+    _block("g2_mfru", lambda sd, x: om.mfru(sd, "", x), _shapes(dict(kind="MFRU")), nin=3)
+
+
+def test_yolov8_3_graph_keys_and_parameter_count():
+    """cfg/models/v8/yolov8-3.yaml at scale l: state_dict key set, shapes and parameter count of the reference model."""
+    g = gold("g2_yolov8_3_keys")
+    plan, save = om.build_plan(load_yaml("yolov8-3.yaml"), scale="l", nc=20)
+    shapes = om.param_shapes(plan)
+    want = {str(k): str(v) for k, v in zip(g["keys"], g["shapes"])}
+    assert set(shapes) == set(want), sorted(set(shapes) ^ set(want))[:6]
+    assert all(str(tuple(shapes[k])) == want[k] for k in shapes)
+    n = sum(int(np.prod(v)) for k, v in shapes.items() if "running_" not in k and "num_batches" not in k and ".dfl." not in k)
+    assert n == int(g["n_params"]) - 16          # the DFL conv weight (16 constants) is a frozen parameter of the reference model
+
+
 def test_asff_detect_goldens():
     sh = _shapes(dict(kind="AsffDetect", nc=5, ch=[16, 32, 32]))
     _block("g2_asffdetect_train", lambda sd, x: om.asff_detect(sd, "", x, 5, [8., 16., 32.], True), sh, nin=3)
