@@ -47,9 +47,9 @@ class Tape:
 
 class _ModuleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, n_in, *args):
+    def forward(ctx, module, n_in, out, *args):
         tape = Tape()
-        outs = module._fwd(tape, *args[:n_in])
+        outs = module._fwd(tape, *args[:n_in]) if out is None else module._fwd(tape, *args[:n_in], out=out)
         ctx.module, ctx.tape, ctx.n_in = module, tape, n_in
         ctx.multi = isinstance(outs, (list, tuple))
         if ctx.multi:
@@ -66,7 +66,7 @@ class _ModuleFn(torch.autograd.Function):
             pass             # the module's backward consumes planar [B,C,H,W] gradients as they are (front-end <- direct stem dgrad)
         else:
             gouts = [as_nhwc(g, m[1]) for g, m in zip(gouts, ctx.out_meta)]
-        gins = module._bwd(tape, *gouts, needs=list(ctx.needs_input_grad[2:2 + ctx.n_in]))
+        gins = module._bwd(tape, *gouts, needs=list(ctx.needs_input_grad[3:3 + ctx.n_in]))
         if not isinstance(gins, (list, tuple)):
             gins = (gins,)
         assert not tape.stack, f"{type(module).__name__}: unbalanced tape"
@@ -74,7 +74,7 @@ class _ModuleFn(torch.autograd.Function):
         if cb is not None:
             cb()                 # data-parallel trainer: this layer's gradients are enqueued -> maybe launch its bucket
         pg = [tape.pgrads.get(p) for p in module._plist]
-        return (None, None, *gins, *pg)
+        return (None, None, None, *gins, *pg)
 
 
 class DyModule(nn.Module):
@@ -88,14 +88,16 @@ class DyModule(nn.Module):
             self.__dict__["_plist"] = pl
         return pl
 
-    def forward(self, x, *extra):
+    def forward(self, x, *extra, out=None):
+        """`out`: optional NHWC view the module's result is written into (GraphPlan: a producer's slice of a yaml-level Concat
+        buffer); only modules whose _fwd takes `out` are called with it."""
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
         xs = [self._adapt(t) for t in xs]
         pl = self._params()
         if torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(p.requires_grad for p in pl)):
-            return self._wrap(_ModuleFn.apply(self, len(xs), *xs, *pl))
+            return self._wrap(_ModuleFn.apply(self, len(xs), out, *xs, *pl))
         with torch.no_grad():
-            return self._wrap(self._fwd(None, *xs))
+            return self._wrap(self._fwd(None, *xs) if out is None else self._fwd(None, *xs, out=out))
 
     def _adapt(self, t):
         return as_nhwc(t, self.in_dtype)
@@ -170,9 +172,30 @@ class Concat(DyModule):
             raise NotImplementedError("Concat: only channel concat is on the hot path")
         self.d = dimension
 
+    @staticmethod
+    def _in_place(xs, tot):
+        """The inputs already ARE the channel slices, in order, of one [B, tot, H, W] NHWC buffer (GraphPlan placed their
+        producers there): return that buffer as a view, else None."""
+        t0 = xs[0]
+        if ld_of(t0) != tot or t0.dim() != 4:
+            return None
+        es, base, o = t0.element_size(), t0.data_ptr(), 0
+        for t in xs:
+            if (t.dtype != t0.dtype or tuple(t.shape[2:]) != tuple(t0.shape[2:]) or t.shape[0] != t0.shape[0] or ld_of(t) != tot
+                    or t.stride() != t0.stride() or t.data_ptr() != base + o * es
+                    or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr()):
+                return None
+            o += t.shape[1]
+        return torch.as_strided(t0, (t0.shape[0], tot, t0.shape[2], t0.shape[3]), t0.stride(), t0.storage_offset())
+
     def _fwd(self, tape, *xs):
         B, _, H, W = xs[0].shape
         tot = sum(t.shape[1] for t in xs)
+        whole = self._in_place(xs, tot)
+        if whole is not None:
+            if tape is not None:
+                tape.push([t.shape[1] for t in xs])
+            return whole
         out = empty_nhwc(B, tot, H, W, xs[0].dtype, xs[0].device)
         o = 0
         for t in xs:
@@ -201,8 +224,8 @@ class Upsample(DyModule):
         self.scale_factor = int(scale_factor)
         self.mode = mode
 
-    def _fwd(self, tape, x):
-        return ops.upsample_fwd(x, self.scale_factor)
+    def _fwd(self, tape, x, out=None):
+        return ops.upsample_fwd(x, self.scale_factor, out=out)
 
     def _bwd(self, tape, dy, needs=None):
         return ops.upsample_bwd(dy, self.scale_factor)
@@ -241,14 +264,14 @@ class C2f(DyModule):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    def _fwd(self, tape, x):
+    def _fwd(self, tape, x, out=None):
         c, n = self.c, len(self.m)
         B, _, H, W = x.shape
         Y = empty_nhwc(B, (2 + n) * c, H, W, x.dtype, x.device)
         self.cv1._fwd(tape, x, out=Y[:, :2 * c])
         for i, m in enumerate(self.m):
             m._fwd(tape, Y[:, (1 + i) * c:(2 + i) * c], out=Y[:, (2 + i) * c:(3 + i) * c])
-        return self.cv2._fwd(tape, Y)
+        return self.cv2._fwd(tape, Y, out=out)
 
     def _bwd(self, tape, dy, needs=(True,)):
         c, n = self.c, len(self.m)
@@ -269,7 +292,7 @@ class SPPF(DyModule):
         self.k = k
         self.c_ = c_
 
-    def _fwd(self, tape, x):
+    def _fwd(self, tape, x, out=None):
         c_, k = self.c_, self.k
         B, _, H, W = x.shape
         Y = empty_nhwc(B, 4 * c_, H, W, x.dtype, x.device)
@@ -281,7 +304,7 @@ class SPPF(DyModule):
             args.append(a)
         if tape is not None:
             tape.push(args)
-        return self.cv2._fwd(tape, Y)
+        return self.cv2._fwd(tape, Y, out=out)
 
     def _bwd(self, tape, dy, needs=(True,)):
         c_, k = self.c_, self.k

@@ -88,9 +88,29 @@ _RULES = {
 _PASS_THROUGH = lambda r: (r.args, r.ch_in[0], r.repeats)         # Upsample, RFBblock: channels unchanged
 
 
+_PLACEABLE = (Conv, C2f, SPPF, Upsample)          # top-level modules whose last kernel can write into a caller-provided NHWC view
+
+
+def _out_hw(m, x):
+    """Spatial size of m(x) for the placeable module types."""
+    H, W = x.shape[2], x.shape[3]
+    if isinstance(m, Conv):
+        c = m.conv
+        k, st, p, d = c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]
+        return (H + 2 * p - d * (k - 1) - 1) // st + 1, (W + 2 * p - d * (k - 1) - 1) // st + 1
+    if isinstance(m, Upsample):
+        return H * m.scale_factor, W * m.scale_factor
+    return H, W
+
+
 class GraphPlan:
     """Flat execution plan of a layer graph: nodes[i] = (module, sources, takes_list); a source is an absolute node index or -1
-    for the network input.  `dead_after[i]` lists the nodes whose outputs have their last consumer at node i."""
+    for the network input.  `dead_after[i]` lists the nodes whose outputs have their last consumer at node i.
+
+    yaml-level Concat without copies: when every source of a Concat node is a Conv / C2f / SPPF / Upsample node that is not already
+    placed elsewhere (and all widths are multiples of 8), `place[s] = (concat node, channel offset)`: node s then writes its output
+    straight into its channel slice of the concat buffer (allocated when the first source runs; other consumers of s read the
+    slice as a strided view), and Concat finds its inputs already in place (reference conv.py:462-473 = torch.cat copies)."""
 
     def __init__(self, layers):
         self.nodes, n = [], len(layers)
@@ -108,12 +128,39 @@ class GraphPlan:
             if 0 <= i < n - 1:
                 self.dead_after[i].append(sidx)
         self.save = sorted({sidx for m, src, _ in self.nodes for sidx, j in zip(src, ([m.f] if isinstance(m.f, int) else m.f)) if j != -1})
+        self.place, self.concat_width = {}, {}
+        for i, (m, src, _) in enumerate(self.nodes):
+            if not isinstance(m, Concat) or len(set(src)) != len(src):
+                continue
+            widths = [getattr(layers[sidx], "c_out", None) if sidx >= 0 else None for sidx in src]
+            ok = all(sidx >= 0 and isinstance(layers[sidx], _PLACEABLE) and sidx not in self.place and w and w % 8 == 0
+                     for sidx, w in zip(src, widths))
+            if not ok:
+                continue
+            off = 0
+            for sidx, w in zip(src, widths):
+                self.place[sidx] = (i, off)
+                off += w
+            self.concat_width[i] = off
 
     def run(self, x, call_layer):
         outs = [None] * len(self.nodes)
+        bufs = {}                                       # concat node -> its buffer of this pass
         for i, (m, src, as_list) in enumerate(self.nodes):
             ins = [x if sidx < 0 else outs[sidx] for sidx in src]
-            outs[i] = call_layer(m, ins if as_list else ins[0])
+            slot = self.place.get(i)
+            if slot is None:
+                outs[i] = call_layer(m, ins if as_list else ins[0])
+            else:
+                c, off = slot
+                buf = bufs.get(c)
+                if buf is None:
+                    t = ins[0]
+                    Ho, Wo = _out_hw(m, t)
+                    buf = bufs[c] = ops.empty_nhwc(t.shape[0], self.concat_width[c], Ho, Wo, ops.get_compute_dtype(), t.device)
+                outs[i] = call_layer(m, ins if as_list else ins[0], out=buf[:, off:off + m.c_out])
+            if i in bufs:
+                del bufs[i]                             # the Concat node has run: its output tensor owns the buffer now
             for sidx in self.dead_after[i]:
                 outs[sidx] = None                     # last consumer done: the buffer goes back to the allocator now
         return outs[-1]
@@ -141,6 +188,7 @@ def parse_model(d, ch, verbose=False):
         layer = nn.Sequential(*(cls(*ctor_args) for _ in range(n_mod))) if n_mod > 1 else cls(*ctor_args)
         layer.np = sum(p.numel() for p in layer.parameters())
         layer.i, layer.f, layer.type = index, src, kind
+        layer.c_out = c_out                       # output channels (GraphPlan places producers inside yaml-level Concat buffers)
         if verbose:
             print(f"{index:>3}{str(src):>20}{row.repeats:>3}{layer.np:10.0f}  {kind:<45}{str(ctor_args):<30}")
         layers.append(layer)
@@ -195,10 +243,10 @@ class BaseModel(nn.Module):
             plan = self.__dict__["_plan"] = GraphPlan(list(self.model))
         eval_front = not self.training
 
-        def call_layer(m, inp):
+        def call_layer(m, inp, out=None):
             if eval_front and isinstance(m, lowlight_recovery):
                 return m(inp, self.current_dedark_A, self.current_IcA)
-            return m(inp)
+            return m(inp) if out is None else m(inp, out=out)
         return plan.run(x, call_layer)
 
     def loss(self, batch, preds=None):
