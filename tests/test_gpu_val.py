@@ -196,6 +196,26 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out          # cpu_baseline is an N=1 field
 
 
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (what a driver without its own launcher runs): bench.py starts a
+    torch.distributed.run child before touching the GPU and exits with its code; one JSON line, two ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DY_SINGLE_DEVICE="1", DY_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--imgsz", "128",
+           "--model", "yolov8n-lowlight.yaml", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["replicas_in_sync"] is True and out["rccl_ranks"] == 0
+
+
 def test_predict_results_vs_oracle_nms():
     """YOLO.predict(): preprocess -> eval forward -> HIP NMS (predictor defaults: multi_label off) -> Results, against the oracle's
     NMS + scale_boxes on the same raw predictions."""
