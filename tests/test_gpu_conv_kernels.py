@@ -107,6 +107,8 @@ ROUTED = [
     ((8, 320, 128, 160, 160, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),
     ((6, 64, 256, 63, 65, 5, 1, 2), (None, None, "wg4::wgrad_kernel")),                                         # 5x5 taps in the mixed-radix walk
     ((8, 1024, 256, 48, 48, 1, 1, 0), (None, None, "wg4::wgrad_kernel")),                                       # pointwise variant
+    ((16, 256, 64, 80, 80, 3, 1, 1), (None, None, "wg4::wgrad_kernel")),                                        # quarter-filled tile, long pixel loop
+    ((12, 320, 128, 80, 80, 1, 1, 0), (None, None, "wg4::wgrad_kernel")),                                       # half-filled, K = 320 (2 tiles, 37 % pad)
 ]
 
 

@@ -46,9 +46,11 @@ def main():
     torch.cuda.synchronize()
     rec, _C._prof = _C._prof, None
     agg = {}
-    for name, e0, e1, meta, _kern in rec:
+    for name, e0, e1, meta, kern in rec:
         key = (name, (meta or {}).get("shape", ""))
-        v = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
+        v = agg.setdefault(key, [0.0, 0, 0.0, 0.0, set()])
+        if kern:
+            v[4].add(kern.split("+")[0])
         v[0] += e0.elapsed_time(e1)
         v[1] += 1
         if meta:
@@ -61,7 +63,7 @@ def main():
         us = 1e3 * v[0] / v[1]
         tf = v[2] / v[1] / (us * 1e-6) / 1e12 if v[2] else 0.0
         gbs = v[3] / v[1] / (us * 1e-6) / 1e9 if v[3] else 0.0
-        print(f"{ms:8.3f} ms/step {v[1] // a.steps:4d}x {us:9.1f} us  {tf:7.1f} TF {gbs:7.0f} GB/s  {name:26s} {shape}")
+        print(f"{ms:8.3f} ms/step {v[1] // a.steps:4d}x {us:9.1f} us  {tf:7.1f} TF {gbs:7.0f} GB/s  {name:26s} {shape}  [{', '.join(sorted(v[4]))}]")
 
 
 if __name__ == "__main__":
