@@ -222,6 +222,8 @@ def workload_tag(args):
         return "BASELINE configs[1] (C2: YOLOv8n + lowlight_recovery front-end)", "c2"
     if key == ("yolov8l.yaml", 640, 64, "bf16"):
         return "BASELINE configs[2] (C3: repo yolov8.yaml@L = lowlight_recovery + ASFF neck)", "c3"
+    if key == ("yolov8nori.yaml", 640, 4, "fp32"):
+        return "BASELINE configs[0] (C1: plain YOLOv8n graph yolov8ori.yaml@n, the reference's CPU-runnable case)", "c1"
     if key == ("yolov8l.yaml", 1280, 16, "fp16"):
         return "BASELINE configs[4] (C5: repo yolov8.yaml@L at 1280x1280, fp16)", "c5"
     return "custom workload", None

@@ -530,7 +530,7 @@ def wgrad_join():
 
 
 # ---- independent branches on their own streams (the three pyramid levels of the Detect head, forward and backward)
-_branch = {"on": False, "streams": []}
+_branch = {"on": False, "streams": [], "by_device": {}}      # "streams": every side stream ever made (arena fills fork to all)
 
 
 def enable_branch_streams(on=True):
@@ -542,9 +542,14 @@ def branch_streams(n, device):
     """n side streams for independent branches, or None when the switch is off."""
     if not _branch["on"] or n <= 0:
         return None
-    while len(_branch["streams"]) < n:
-        _branch["streams"].append(torch.cuda.Stream(device=device))
-    return _branch["streams"][:n]
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    mine = _branch["by_device"].setdefault(key, [])            # a stream belongs to ONE device: one list per ordinal
+    while len(mine) < n:
+        s = torch.cuda.Stream(device=device)
+        mine.append(s)
+        _branch["streams"].append(s)
+    return mine[:n]
 
 
 def _grad_dst(p):
