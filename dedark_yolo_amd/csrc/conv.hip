@@ -761,40 +761,85 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
-// all weights of a model in one launch: block b belongs to the item with first_block <= b < next.first_block
-constexpr int PACK_PER_BLOCK = 1024;
+// all weights of a model in one launch: block b belongs to the item with first_block <= b < next.first_block.
+// A block = one 32 (output channels) x 32 (input channels) tile of one weight, all taps: the OIHW source rows of the tile are
+// contiguous runs of 32 * KH * KW floats (read coalesced into LDS), the packed destination -- [Cout_pad][KH][KW][Cin_pad] or the
+// transposed [Cin_pad][KH][KW][Cout_pad] -- is written in runs of 32 consecutive elements read back from LDS.  (The first version
+// computed one output element per thread and gathered its source with a 36-byte stride: 2.5 GB of fetch traffic per launch by
+// PMC for 0.35 GB of weights.  The launch itself still takes ~0.5 ms per C3 step with either version -- not yet understood.)
+// Windows of more than PACK_TAPS taps (the extractor's 8x8 fully connected layer) go through in tap chunks.
+constexpr int PACK_TILE = 32, PACK_TAPS = 9;
+
+__device__ inline void pack_store(const dy_pack_item& it, long o, float v) {
+  if (it.dtype == DY_F32) ((float*)it.packed)[o] = v;
+  else if (it.dtype == DY_F16) ((f16_t*)it.packed)[o] = (f16_t)v;
+  else ((bf16_t*)it.packed)[o] = f32_to_bf16(v);
+}
+
+// one chunk of TC taps [t0, t0 + TC) of the block's 32 x 32 tile.  TC is a compile-time constant for the windows that matter
+// (1x1, 3x3), so that the index arithmetic has no run-time divisions.  TC == 0: run-time `tc`.
+template <int TC>
+__device__ inline void pack_chunk(const dy_pack_item& it, float (&tile)[PACK_TILE][PACK_TILE * PACK_TAPS + 1], int co0, int ci0, int T,
+                                  int t0, int tc_rt) {
+  const int tc = TC ? TC : tc_rt;
+  const int tid = threadIdx.x;
+  const int run = PACK_TILE * tc;
+  {   // read: 8 threads per source row (row co of the tile = `run` consecutive floats when tc == T)
+    const int r = tid >> 3, co = co0 + r;
+    const bool row_ok = co < it.Cout;
+    const float* src = it.w + ((long)co * it.Cin + ci0) * T + t0;
+    for (int k = tid & 7; k < run; k += 8) {
+      const int cl = k / tc, t = k - cl * tc;
+      const int ci = ci0 + cl;
+      float v = 0.f;
+      if (row_ok && ci < it.Cin) v = src[(long)cl * T + t];
+      tile[r][cl * PACK_TAPS + t] = v;
+    }
+  }
+  __syncthreads();
+  const int n_out = PACK_TILE * PACK_TILE * tc;
+  if (!it.transposed) {                            // packed[co][tap][ci]: 32 consecutive ci per (co, tap)
+    for (int i = tid; i < n_out; i += 256) {
+      const int cl = i & (PACK_TILE - 1), rt = i >> 5;
+      const int r = rt / tc, t = rt - r * tc;
+      const int co = co0 + r, ci = ci0 + cl;
+      if (co < it.Cout_pad && ci < it.Cin_pad) pack_store(it, ((long)co * T + t0 + t) * it.Cin_pad + ci, tile[r][cl * PACK_TAPS + t]);
+    }
+  } else {                                         // packed[ci][tap][co]: 32 consecutive co per (ci, tap)
+    for (int i = tid; i < n_out; i += 256) {
+      const int r = i & (PACK_TILE - 1), ct = i >> 5;
+      const int cl = ct / tc, t = ct - cl * tc;
+      const int co = co0 + r, ci = ci0 + cl;
+      if (co < it.Cout_pad && ci < it.Cin_pad) pack_store(it, ((long)ci * T + t0 + t) * it.Cout_pad + co, tile[r][cl * PACK_TAPS + t]);
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(const dy_pack_item* __restrict__ items, int n_items) {
-  int lo = 0, hi = n_items - 1;
+  __shared__ float tile[PACK_TILE][PACK_TILE * PACK_TAPS + 1];          // [co][ci * taps + t]; +1: conflict-free transposed reads
+  // the block's item: last one with first_block <= b; the first_block values go through LDS in one round trip
+  __shared__ long fb[1024];
   const long b = blockIdx.x;
-  while (lo < hi) {                      // last item with first_block <= b
+  const bool cached = n_items <= 1024;
+  if (cached) {
+    for (int i = threadIdx.x; i < n_items; i += 256) fb[i] = items[i].first_block;
+    __syncthreads();
+  }
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    if ((cached ? fb[mid] : items[mid].first_block) <= b) lo = mid; else hi = mid - 1;
   }
   const dy_pack_item it = items[lo];
-  const long total = (long)it.Cout_pad * it.KH * it.KW * it.Cin_pad;
-  const long base = (b - it.first_block) * PACK_PER_BLOCK;
-#pragma unroll
-  for (int k = 0; k < PACK_PER_BLOCK / 256; ++k) {
-    const long i = base + k * 256 + threadIdx.x;
-    if (i >= total) break;
-    int co, kh, kw, ci;
-    long r = i;
-    if (!it.transposed) {
-      ci = (int)(r % it.Cin_pad); r /= it.Cin_pad;
-      kw = (int)(r % it.KW); r /= it.KW;
-      kh = (int)(r % it.KH); r /= it.KH;
-      co = (int)r;
-    } else {
-      co = (int)(r % it.Cout_pad); r /= it.Cout_pad;
-      kw = (int)(r % it.KW); r /= it.KW;
-      kh = (int)(r % it.KH); r /= it.KH;
-      ci = (int)r;
-    }
-    const float v = (ci < it.Cin && co < it.Cout) ? it.w[(((long)co * it.Cin + ci) * it.KH + kh) * it.KW + kw] : 0.f;
-    if (it.dtype == DY_F32) ((float*)it.packed)[i] = v;
-    else if (it.dtype == DY_F16) ((f16_t*)it.packed)[i] = (f16_t)v;
-    else ((bf16_t*)it.packed)[i] = f32_to_bf16(v);
-  }
+  const int tiles_ci = (it.Cin_pad + PACK_TILE - 1) / PACK_TILE;
+  const int tb = (int)(b - it.first_block);
+  const int co0 = (tb / tiles_ci) * PACK_TILE, ci0 = (tb % tiles_ci) * PACK_TILE;
+  const int T = it.KH * it.KW;
+  if (T == 9) pack_chunk<9>(it, tile, co0, ci0, 9, 0, 9);
+  else if (T == 1) pack_chunk<1>(it, tile, co0, ci0, 1, 0, 1);
+  else
+    for (int t0 = 0; t0 < T; t0 += PACK_TAPS) pack_chunk<0>(it, tile, co0, ci0, T, t0, T - t0 < PACK_TAPS ? T - t0 : PACK_TAPS);
 }
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cout, int Cin, int Cin_pad,
@@ -1138,7 +1183,8 @@ extern "C" int dy_pack_weight(const float* w, void* packed, int Cout, int Cout_p
 }
 
 extern "C" int64_t dy_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW) {
-  return ((int64_t)Cout_pad * KH * KW * Cin_pad + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK;
+  (void)KH; (void)KW;                       // one block per 32 x 32 channel tile, whatever the window
+  return (int64_t)((Cout_pad + PACK_TILE - 1) / PACK_TILE) * ((Cin_pad + PACK_TILE - 1) / PACK_TILE);
 }
 
 extern "C" int dy_pack_weights_multi(const dy_pack_item* items_dev, int n_items, int64_t n_blocks, void* stream) {

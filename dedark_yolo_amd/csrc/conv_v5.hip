@@ -124,16 +124,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
   auto advance = [&]() {
     ++sk;
-    s_ci += BK;
-    a_koff += BK * 2;
-    b_koff += BK * 2;
-    if (s_ci >= p.Cs) {
-      s_ci = 0;
-      ++s_bit;
-      if (++s_tw == p.KW) { s_tw = 0; ++s_th; }
-      a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2;
-      b_koff = (unsigned)(((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs * 2);
+    // K order: all taps of one BK-channel chunk, then the next chunk.  The taps re-read the SAME pixels (shifted windows), so with
+    // the taps innermost a tile's live set is (tile + halo) x BK channels (~40 KB; 32 CUs x 40 KB sit in an XCD's 4 MiB L2) and
+    // the 2nd .. 9th reads are L2 hits; tap-major order cycled through the tile's full channel depth between two reads of a
+    // line (150 KB per CU: more than its L2 share -> every tap went back to the Infinity Cache, 2.4x fabric traffic).
+    ++s_bit;
+    if (++s_tw == p.KW) {
+      s_tw = 0;
+      if (++s_th == p.KH) { s_th = 0; s_bit = 0; s_ci += BK; }
     }
+    a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2 + s_ci * 2;
+    b_koff = (unsigned)((((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs + s_ci) * 2);
     if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a stage nobody reads again)
       s_bit = 31;
       b_koff = 0x80000000u;

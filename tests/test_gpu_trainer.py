@@ -426,3 +426,36 @@ def test_train_loop_validates_on_ema_weights_and_tracks_best(tmp_path):
         assert abs(got["fitness"] - tr.fitness) <= 2e-3, (got["fitness"], tr.fitness)        # checkpoint weights are fp16
     finally:
         dy.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_multi_pack_equals_single_pack(dtype):
+    """dy_pack_weights_multi (one launch re-packing every weight of the model after the optimizer step: LDS-tiled transposes, both
+    layouts, all dtypes, 1x1 / 3x3 / the extractor's 8x8 window, ragged channel counts) against dy_pack_weight of each weight."""
+    import bench
+    from dedark_yolo_amd import ops
+    from dedark_yolo_amd._C import call
+    from dedark_yolo_amd.ops import ptr, stream
+    tr = _tiny_trainer("SGD", batch=64, dtype=dtype)
+    try:
+        b = bench.synth_batch(31, 2, 64, 20, "cuda")
+        tr.args.dark_param = b.pop("gamma")
+        b.pop("n_max", None)
+        tr.train_step(b, [0.01] * 3, 0.9)                    # creates the packed copies (both layouts) and runs the multi-pack
+        torch.cuda.synchronize()
+        ent = tr.pack_plan._collect(tr.model)
+        assert len(ent) > 40
+        seen = set()
+        for w, (cout_pad, cin_pad, transposed, dt), out in ent:
+            Co, Ci, KH, KW = w.shape
+            ref = torch.empty_like(out)
+            call("dy_pack_weight", ptr(w.detach().float().contiguous()), ptr(ref), Co, cout_pad, Ci, cin_pad, KH, KW, 1 if transposed else 0,
+                 ops.dt_id(dt), stream())
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16 if out.element_size() == 2 else torch.int32),
+                               ref.view(torch.int16 if ref.element_size() == 2 else torch.int32)), (tuple(w.shape), cout_pad, cin_pad, transposed)
+            seen.add((KH, bool(transposed)))
+        assert {(1, False), (3, False), (3, True), (8, False)} <= seen, seen
+    finally:
+        import dedark_yolo_amd as dy
+        dy.set_compute_dtype(torch.float32)
