@@ -14,6 +14,8 @@ SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_
 step() { echo "[profile_round] $1 ($(date +%T))"; }
 step "kernel stats C3" &&
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3_stats" -o c3 -- python3 "$ROOT/bench.py" $STATS > "$OUT/bench_c3_under_rocprof.log" 2>&1 &&
+step "kernel stats C3, one stream (the schedule bench.py's roofline leg times: averages comparable with its avg_launch_us)" &&
+DY_WGRAD_STREAM=0 DY_BRANCH_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3s_stats" -o c3s -- python3 "$ROOT/bench.py" $STATS > "$OUT/bench_c3_single_stream_under_rocprof.log" 2>&1 &&
 step "kernel stats C2" &&
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2_stats" -o c2 -- python3 "$ROOT/bench.py" $C2 $STATS > "$OUT/bench_c2_under_rocprof.log" 2>&1 &&
 step "PMC C3" &&
@@ -34,7 +36,8 @@ python3 tools/pmc_traffic.py $(find "$OUT/c2_f" -name "*counter_collection.csv" 
 python3 tools/pmc_traffic.py $(find "$OUT/c3_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c3_w" -name "*counter_collection.csv" | head -1) "$OUT/c3_pmc_traffic.json" > "$OUT/pmc_c3_summary.log" 2>&1 &&
 cp $(find "$OUT/c2_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c2_kernel_stats.csv" &&
 cp $(find "$OUT/c3_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c3_kernel_stats.csv" &&
-rm -rf "$OUT"/c2_stats "$OUT"/c3_stats "$OUT"/c2_f "$OUT"/c2_w "$OUT"/c3_f "$OUT"/c3_w "$OUT"/sq_*/ &&
+cp $(find "$OUT/c3s_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c3_single_stream_kernel_stats.csv" &&
+rm -rf "$OUT"/c2_stats "$OUT"/c3_stats "$OUT"/c3s_stats "$OUT"/c2_f "$OUT"/c2_w "$OUT"/c3_f "$OUT"/c3_w "$OUT"/sq_*/ &&
 step "plain bench lines" &&
 python3 bench.py > "$OUT/bench_c3.json.log" 2> "$OUT/bench_c3.err" &&
 python3 bench.py $C2 --steps 100 --warmup 20 > "$OUT/bench_c2.json.log" 2> "$OUT/bench_c2.err"
