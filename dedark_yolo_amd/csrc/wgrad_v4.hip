@@ -379,9 +379,10 @@ bool dy_wgrad_v4_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
   // 256-wide tiles must not be mostly padding (Cout >= 192 within 20 %, K within 20 %) and the pixel loop must be long enough to
   // amortise a slab -- except against the 128 x 128 kernel on long pixel loops: there even a quarter-filled tile wins (C3, B = 64:
   // 256->64 3x3 at 80x80 672 -> 365 us, 512->64 at 40x40 338 -> 196, 320->128 1x1 at 160x160 436 -> 321, 64->128 3x3 s2 at 320x320
-  // 829 -> 521), so from 65,536 pixels on any Cout >= 64 and any K >= 192 is taken.
+  // 829 -> 521), so from 65,536 pixels on any Cout >= 64 and K >= 192 is taken
   const bool tight = Cout_pad >= 192 && tq * 256 * 4 <= (long)Cout_pad * 5 && tp * 256 * 4 <= Ktot * 5;
-  const bool long_loop = Cout_pad >= 64 && M >= 65536;
+  // ... as long as the tile is at least a quarter full (32->64 3x3 s2 at 160x160, B = 32: K = 288, 14 % full, 48 -> 135 us: not taken)
+  const bool long_loop = Cout_pad >= 64 && M >= 65536 && Ktot * Cout_pad * 4 >= tp * 256 * tq * 256;
   if (!(Ktot >= 192 && (tight || long_loop))) return false;
   if (M < 16384 || M >= (1L << 31)) return false;
   const long x_bytes = (((long)N * Hi * Wi - 1) * x_ld + Cin_pad) * 2, dz_bytes = ((M - 1) * dz_ld + Cout_pad) * 2;
