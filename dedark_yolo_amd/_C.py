@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
                 ("dst_ld", i64), ("Hd", i32), ("Wd", i32), ("Cd", i32), ("KH", i32), ("KW", i32), ("stride", i32),
                 ("pad", i32), ("dil", i32), ("scale", vp), ("shift", vp), ("act", i32), ("stats", vp), ("accumulate", i32),
                 ("dtype", i32), ("dst_row_stride", i64), ("dst_img_stride", i64), ("KHf", i32), ("KWf", i32), ("kh0", i32),
-                ("kh_step", i32), ("kw0", i32), ("kw_step", i32), ("dst_valid_channels", i32), ("dst_planar", vp)]
+                ("kh_step", i32), ("kw0", i32), ("kw_step", i32), ("dst_valid_channels", i32), ("dst_planar", vp),
+                ("add_src", vp), ("add_src_ld", i64)]
 
 
 class PackItem(C.Structure):

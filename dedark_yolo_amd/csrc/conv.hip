@@ -988,7 +988,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   return d->dtype == DY_F32 ? launch_conv<float, 0>(d, st) : (d->dtype == DY_F16 ? launch_conv<f16_t, 0>(d, st) : launch_conv<bf16_t, 0>(d, st));
 }
 
-extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
+static int dgrad_dispatch(const dy_conv_desc* d, void* stream, bool* added) {
   if (int e = check_conv(d, "dy_conv2d_dgrad")) return e;
   // src = dz (conv output geometry), dst = dx (conv input geometry)
   const int ho = (d->Hd + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
@@ -1075,13 +1075,24 @@ extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
       return 0;
     }
   }
-  if (dy_conv_v4_eligible(d, 1)) return dy_conv_v4_launch(d, 1, stream);
-  if (dy_conv_v5_eligible(d, 1)) return dy_conv_v5_launch(d, 1, stream);
+  // the two large-tile kernels add the optional `add_src` view in their epilogue
+  if (dy_conv_v4_eligible(d, 1)) { *added = true; return dy_conv_v4_launch(d, 1, stream); }
+  if (dy_conv_v5_eligible(d, 1)) { *added = true; return dy_conv_v5_launch(d, 1, stream); }
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);
   if (dy_conv_v2_eligible(d)) return dy_conv_v2_launch(d, 1, stream);
   hipStream_t st = (hipStream_t)stream;
   if (thin_eligible(d, 1)) return launch_thin(d, 1, st);
   return d->dtype == DY_F32 ? launch_conv<float, 1>(d, st) : (d->dtype == DY_F16 ? launch_conv<f16_t, 1>(d, st) : launch_conv<bf16_t, 1>(d, st));
+}
+
+extern "C" int dy_conv2d_dgrad(const dy_conv_desc* d, void* stream) {
+  bool added = false;
+  if (int e = dgrad_dispatch(d, stream, &added)) return e;
+  if (d->add_src && !added) {           // route without the fused addend: dst += add_src as its own pass
+    DY_CHECK(d->dst && d->dst_planar == nullptr, "dy_conv2d_dgrad: add_src needs an NHWC destination");
+    return dy_copy2d(d->add_src, d->add_src_ld, d->dst, d->dst_ld, (int64_t)d->N * d->Hd * d->Wd, d->Cd, 1, d->dtype, stream);
+  }
+  return 0;
 }
 
 namespace {

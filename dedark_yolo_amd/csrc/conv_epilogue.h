@@ -86,8 +86,11 @@ constexpr int row_pitch() { return BN * 2 + 8; }
 template <int BM, int BN>
 constexpr int row_image_bytes() { return BM * row_pitch<BN>(); }
 
+// `add` (optional): a second [pixel][channel] view (pixel stride add_ld) whose values are added on the way out -- dst = [dst +]
+// tile + add (the shortcut gradient of a Bottleneck joins the data gradient of its first conv here instead of in a copy pass).
 template <int BM, int BN, int NW, typename T16, typename OffFn>
-__device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, T16* dst, OffFn off) {
+__device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, T16* dst, OffFn off,
+                                  const T16* __restrict__ add = nullptr, long add_ld = 0) {
   constexpr int PT = row_pitch<BN>();
   constexpr int LPP = BN >= 128 ? 16 : BN / 8;      // lanes (16-byte chunks) per pixel and instruction: 16 (256 B) or 8 (BN = 64: 128 B)
   constexpr int PPI = 64 / LPP;                     // pixels per wave instruction
@@ -108,21 +111,30 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
         u32x4 v = {lo.x, lo.y, hi.x, hi.y};
         T16* o = dst + off(m) + n;
         if (n + 8 <= Cd) {
-          if (accumulate) {
+          if (accumulate || add) {
             float x[8], y[8];
-            ldvec<T16>(o, x);
             ldvec<T16>(reinterpret_cast<const T16*>(&v), y);
+            if (accumulate) {
+              ldvec<T16>(o, x);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += y[e];
-            stvec<T16>(o, x);
+              for (int e = 0; e < 8; ++e) y[e] += x[e];
+            }
+            if (add) {
+              ldvec<T16>(add + m * add_ld + n, x);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] += x[e];
+            }
+            stvec<T16>(o, y);
           } else {
             *reinterpret_cast<u32x4*>(o) = v;
           }
         } else {
           const T16* e = reinterpret_cast<const T16*>(&v);
           for (int q = 0; q < 8 && n + q < Cd; ++q) {
-            if (accumulate) DT<T16>::st(o + q, DT<T16>::ld(o + q) + DT<T16>::ld(e + q));
-            else o[q] = e[q];
+            float t = DT<T16>::ld(e + q);
+            if (accumulate) t += DT<T16>::ld(o + q);
+            if (add) t += DT<T16>::ld(add + m * add_ld + n + q);
+            DT<T16>::st(o + q, t);
           }
         }
       }

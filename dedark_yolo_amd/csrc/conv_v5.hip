@@ -50,6 +50,8 @@ struct P {
   long M;
   int nk;                        // K-steps = KH*KW*Cs/32
   int tiles_n, nblk;
+  const char* add_src;           // optional addend view of a data gradient (dy_conv_desc.add_src)
+  long add_src_ld;
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   }
   __syncthreads();
   dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
-                                [&](long m) { return dst_offset(p, m); });
+                                [&](long m) { return dst_offset(p, m); }, reinterpret_cast<const T*>(p.add_src), p.add_src_ld);
   if (p.stats) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
@@ -314,6 +316,7 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   p.w_bytes = (unsigned)((long)d->Cd * p.w_row * 2);
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
+  p.add_src = mode == 1 ? (const char*)d->add_src : nullptr; p.add_src_ld = d->add_src_ld;
   p.nk = d->KH * d->KW * d->Cs / v5::BK;
   p.dst_row = d->dst_row_stride;
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;

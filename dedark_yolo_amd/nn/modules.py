@@ -140,8 +140,8 @@ class Conv(DyModule):
         return conv_forward(tape, x, c.weight, None, self.bn, self._act, c.stride[0], c.padding[0], c.dilation[0],
                             self.training, out=out, residual=residual)
 
-    def _bwd(self, tape, dy, needs=(True,), dx_out=None, accumulate=False):
-        return conv_backward(tape, dy, need_dx=needs[0], dx_out=dx_out, accumulate=accumulate)
+    def _bwd(self, tape, dy, needs=(True,), dx_out=None, accumulate=False, add_src=None):
+        return conv_backward(tape, dy, need_dx=needs[0], dx_out=dx_out, accumulate=accumulate, add_src=add_src)
 
 
 class AddConv(nn.Module):
@@ -247,10 +247,8 @@ class Bottleneck(DyModule):
 
     def _bwd(self, tape, dy, needs=(True,), dx_out=None, accumulate=False):
         dt = self.cv2._bwd(tape, dy)
-        dx = self.cv1._bwd(tape, dt, dx_out=dx_out, accumulate=accumulate)
-        if self.add:
-            copy2d(dy, dx, accumulate=True)
-        return dx
+        # shortcut: dx = d cv1 + dy, added inside cv1's data gradient (dy_conv_desc.add_src) instead of by a copy pass
+        return self.cv1._bwd(tape, dt, dx_out=dx_out, accumulate=accumulate, add_src=dy if self.add else None)
 
 
 class C2f(DyModule):

@@ -559,9 +559,11 @@ def _grad_dst(p):
     return None
 
 
-def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
+def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src=None):
     """Backward of the matching conv_forward (pops its context). dy: NHWC view of the gradient wrt the conv's output
-    (for a residual conv the caller routes dy to the residual branch itself). Returns dx (NHWC view) or None."""
+    (for a residual conv the caller routes dy to the residual branch itself). Returns dx (NHWC view) or None.
+    add_src: optional NHWC view of dx's shape added to the data gradient in the same call (dx = [dx_out +] dgrad + add_src): the
+    shortcut gradient of a Bottleneck."""
     ctx = tape.pop()
     x = ctx.x
     dtype = x.dtype
@@ -662,7 +664,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     wt = _pack(ctx.weight, cout_pad, cin_pad, True, dtype)
     # network stem (3 -> c, 3x3 stride 2): the direct kernel writes dx planar [B,Cin,H,W], the layout the front-end's
     # backward consumes (6 B/pixel instead of a 16 B NHWC8 vector that is 5/8 padding)
-    planar = (dx_out is None and dtype == torch.bfloat16 and cin_pad == 8 and Cin <= 4 and (KH, KW) == (3, 3) and ctx.stride == 2
+    planar = (dx_out is None and add_src is None and dtype == torch.bfloat16 and cin_pad == 8 and Cin <= 4 and (KH, KW) == (3, 3) and ctx.stride == 2
               and ctx.pad == 1 and ctx.dil == 1 and cout_pad in (16, 32, 64) and os.environ.get("DY_NO_CONV_SMALL") is None)
     if planar:
         dxp = torch.empty((B, Cin, H, W), dtype=dtype, device=dev)
@@ -684,6 +686,10 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False):
     d = _conv_desc(dz, wt, dxb, B, Ho, Wo, cout_pad, H, W, cin_pad, KH, KW, ctx.stride, ctx.pad, ctx.dil, None, None, ACT_NONE,
                    None, accumulate, dtype)
     d.dst_valid_channels = Cin
+    if add_src is not None:
+        if tuple(add_src.shape) != (B, Cin, H, W) or add_src.dtype != dtype or padded_channels(add_src) != cin_pad:
+            raise RuntimeError("conv_backward: add_src must be an NHWC view of dx's shape and dtype")
+        d.add_src, d.add_src_ld = add_src.data_ptr(), ld_of(add_src)
     _C._prof is not None and _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                 bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)

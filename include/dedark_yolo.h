@@ -67,6 +67,10 @@ typedef struct {
   void* dst_planar;       /* dy_conv2d_dgrad only, optional: write dx as PLANAR [N, dst_valid_channels, Hd, Wd] (compute dtype)
                              instead of the NHWC view `dst` (which may then be NULL).  Only the direct stem kernel (3x3,
                              stride 2, pad 1, <= 8 padded input channels, bf16) supports it; otherwise the call fails. */
+  const void* add_src;    /* dy_conv2d_dgrad only, optional: a [N,Hd,Wd,Cd] view (pixel stride add_src_ld, compute dtype) added to */
+  int64_t add_src_ld;     /* the result: dst = [dst +] dx + add_src.  Bottleneck's shortcut gradient (U/nn/modules/block.py:565:
+                             x + cv2(cv1(x))) joins the data gradient of cv1 this way instead of through a separate pass; the
+                             large-tile kernels add it in their epilogue, other routes run dy_copy2d(accumulate) afterwards. */
 } dy_conv_desc;
 
 /* forward: dst[n,ho,wo,:] = epilogue( sum_{kh,kw,c} src[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c] * w[:,kh,kw,c] ) */

@@ -331,3 +331,47 @@ def test_ciou_and_dfl_entries_on_reference_vectors():
     close(pd.grad.cpu(), g["dfl_grad"], 1e-5, 1e-6, "d dfl / d logits")
     with pytest.raises(NotImplementedError):
         bbox_iou(b1, g["b2"].cuda(), xywh=True, CIoU=True)
+
+
+@pytest.mark.parametrize("c,hw,B", [(128, 80, 16), (256, 40, 32), (64, 160, 8)])
+def test_c2f_shortcut_on_large_tile_kernels_vs_fp32(c, hw, B):
+    """C2f with shortcut Bottlenecks at sizes where the data gradients run on conv_v5 / conv_v4: the shortcut gradient is added in the
+    epilogue of cv1's data gradient (dy_conv_desc.add_src) together with the accumulation into C2f's gradient buffer.  Reference: the
+    same module in fp32 (generic kernels; there the addend is a separate dy_copy2d pass behind the same call).  bf16 bounds of the
+    block table above."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd import _C
+    from dedark_yolo_amd.nn.modules import C2f
+    torch.manual_seed(c)
+    m = C2f(c, c, 2, True).cuda().train()
+    x0 = torch.randn(B, c, hw, hw, device="cuda")
+    gy = torch.randn(B, c, hw, hw, device="cuda")
+
+    def run(dtype, log=False):
+        dy.set_compute_dtype(dtype)
+        for p in m.parameters():
+            p.grad = None
+        for b in m.modules():
+            if isinstance(b, torch.nn.BatchNorm2d):
+                b.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        if log:
+            _C._prof = []
+        y = m(x)
+        y.backward(gy.to(y.dtype))
+        torch.cuda.synchronize()
+        rec, _C._prof = _C._prof, None
+        return y.detach().float(), x.grad.float(), {k: p.grad.float().clone() for k, p in m.named_parameters()}, rec
+
+    try:
+        y1, dx1, g1, rec = run(torch.bfloat16, log=True)
+        y0, dx0, g0, _ = run(torch.float32)
+    finally:
+        _C._prof = None
+    kerns = {r[4] for r in rec if r[0] == "dy_conv2d_dgrad"}
+    assert any(k.startswith("v4::") or k.startswith("v5::") for k in kerns), kerns
+    assert "dy_copy2d" not in [r[0] for r in rec], "the shortcut gradient must not need a copy pass on this path"
+    e_y, e_dx = _rel(y1, y0), _rel(dx1, dx0)
+    e_dp = max(_rel(g1[k], g0[k]) for k in g0)
+    print(f"C2f({c}) {hw}x{hw} B={B}: forward {e_y:.2e} dx {e_dx:.2e} dparam {e_dp:.2e}; dgrad kernels {sorted(kerns)}")
+    assert e_y <= 2e-2 and e_dx <= 3e-2 and e_dp <= 3e-2, (e_y, e_dx, e_dp)
