@@ -314,8 +314,6 @@ struct Geo { int cgb, rows; dim3 grid; };
 // kernel ends with 2 atomics per channel, so wide tensors want FEWER, longer-running blocks: about 2^18 / C of them (2048 at
 // C <= 128 ... 512 at C = 512), never fewer than 4 pixels per thread.  E.g. apply on 512ch x 102,400 px: 6,400 blocks 118 us,
 // 1,024 blocks 82 us; reduce on 64ch x 6.5 M px: 1,024 blocks 429 us, 2,048 blocks 363 us.
-// Below ~128 MB per tensor the backward kernels are dominated by that per-block work (the atomics of the reduce kernel
-// serialise per address: 2,048 blocks / 8 replicas = 256 deep): 512 blocks there (n-scale 64ch x 204,800 px reduce: 52 -> 26 us).
 Geo geometry(long pixels, int C, int ve, int kind /*0 fwd, 1 bwd reduce, 2 bwd apply*/) {
   Geo g;
   const int CG = C / ve;
@@ -325,11 +323,14 @@ Geo geometry(long pixels, int C, int ve, int kind /*0 fwd, 1 bwd reduce, 2 bwd a
   long target = (1L << 18) / (C > 0 ? C : 1);
   target = target > 2048 ? 2048 : (target < 256 ? 256 : target);
   const long bytes = pixels * C * (ve == 8 ? 2 : 4);
-  if (kind != 0 && bytes <= (128L << 20) && target > 512) target = 512;
-  // the reduce kernel of a small tensor is all tail (LDS atomics -> 2 device-scope f64 atomics per channel and block):
-  // 64ch x 51,200 px 15.9 us with 512 blocks, 12.1 us with 256; 256ch x 12,800 px 16.3 -> 12.4 us
-  static const long small_reduce = dy_env("DY_BN_SMALL_REDUCE") ? atol(dy_env("DY_BN_SMALL_REDUCE")) : (16L << 20);
-  if (kind == 1 && bytes <= small_reduce && target > 256) target = 256;
+  // Backward kernels below ~128 MB per tensor (re-swept in round 2 with tools/bn_bench after the reduce kernel lost its LDS float
+  // atomics, whose per-block tail had favoured few blocks): 1,024 blocks from 16 MB on (reduce 128ch x 409,600 px 44.9 -> 37.0 us,
+  // 256ch x 102,400 px 25.9 -> 22.9, 512ch x 102,400 px 48.0 -> 39.5; apply 3-6 %), 512 below (reduce 128ch x 51,200 px 11.3 ->
+  // 8.6 us against the former 256); 512-channel tensors up to 32 MB keep 512 (1,024 atomics per block: 18.4 vs 19.2 us).
+  if (kind != 0 && bytes <= (128L << 20)) {
+    const bool big = bytes > (16L << 20) && !(C >= 512 && bytes <= (32L << 20));
+    target = big ? 1024 : 512;
+  }
   if (env_tgt > 0) target = env_tgt;
   const int gy = dy_cdiv(CG, g.cgb);
   long gx = (target + gy - 1) / gy;
@@ -404,6 +405,19 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   size_t shm = (4 + 2 * (size_t)g.rows) * g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel("bn_act_bwd_reduce_kernel");
+  static const int env_u = dy_env("DY_BN_REDUCE_U") ? atoi(dy_env("DY_BN_REDUCE_U")) : 0;      // (DIAG builds: sweep aid)
+  if (env_u == 4 && dtype == DY_BF16) {
+    bn_act_bwd_reduce_kernel<bf16_t, 4><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
+                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+    DY_LAUNCH_CHECK();
+    return 0;
+  }
+  if (env_u == 1 && dtype == DY_BF16) {
+    bn_act_bwd_reduce_kernel<bf16_t, 1><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
+                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+    DY_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == DY_F32)
     bn_act_bwd_reduce_kernel<float, 2><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
                                                                 invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "../include/dedark_yolo.h"
 
@@ -21,13 +22,16 @@ int main(int argc, char** argv) {
       {"n P5 256@20", 32, 256, 20}, {"L P1 64@320", 64, 64, 320}, {"L P2 128@160", 64, 128, 160}, {"L P3 256@80", 64, 256, 80},
       {"L P4 512@40", 64, 512, 40}, {"L P5 512@20", 64, 512, 20}, {"n 64@40", 32, 64, 40}, {"n 128@20", 32, 128, 20}, {"n 64@20", 32, 64, 20},
       {"n 32@80", 32, 32, 80},
+      {"L 128@80", 64, 128, 80}, {"L 256@40", 64, 256, 40}, {"L 64@160", 64, 64, 160}, {"L 256@20", 64, 256, 20},
   };
+  const char* only = getenv("BB_ONLY");
   hipStream_t st;
   CK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (auto& s : shapes) {
+    if (only && !strstr(s.name, only)) continue;
     const long pixels = (long)s.B * s.H * s.H, n = pixels * s.C;
     unsigned short *z, *y, *dy, *dz;
     float *scale, *shift, *mean, *invstd, *gamma, *dgamma, *dbeta;
