@@ -167,20 +167,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  issue(STAGE);
-  int cur = 0, fill = 2 * STAGE;
-  for (int kt = 0; kt < p.nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + B_LD) : "memory");      // everything but the youngest stage: K-step kt has landed
-    __builtin_amdgcn_s_barrier();                          // ... for every wave; and every wave is done reading K-step kt - 1
-    __builtin_amdgcn_sched_barrier(0);
-    issue(fill);                                           // K-step kt + 2 into the stage K-step kt - 1 occupied
-    __builtin_amdgcn_sched_barrier(0);
+  auto compute = [&](int base) {               // one staged K-step: 4 + MB fragment reads, MB x 4 MFMAs
     u32x4 bfr[NB], afr[MB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + cur + b_rd + 1024 * j);
+    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + base + b_rd + 1024 * j);
 #pragma unroll
-    for (int i = 0; i < MB; ++i) afr[i] = *reinterpret_cast<const u32x4*>(smem + cur + a_rd + 1024 * i);
+    for (int i = 0; i < MB; ++i) afr[i] = *reinterpret_cast<const u32x4*>(smem + base + a_rd + 1024 * i);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -189,9 +181,42 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
         // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
         acc[i][j] = mfma_16x16x32<T>(bfr[j], afr[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = cur == 2 * STAGE ? 0 : cur + STAGE;
-    fill = fill == 2 * STAGE ? 0 : fill + STAGE;
+  };
+  if constexpr (BN >= 128) {
+    issue(0);
+    issue(STAGE);
+    int cur = 0, fill = 2 * STAGE;
+    for (int kt = 0; kt < p.nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + B_LD) : "memory");    // everything but the youngest stage: K-step kt has landed
+      __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading K-step kt - 1
+      __builtin_amdgcn_sched_barrier(0);
+      issue(fill);                                         // K-step kt + 2 into the stage K-step kt - 1 occupied
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == 2 * STAGE ? 0 : cur + STAGE;
+      fill = fill == 2 * STAGE ? 0 : fill + STAGE;
+    }
+  } else {
+    // 64-wide tiles: a wave has only 16 MFMAs per K-step, less than the fixed cost of a step (wait + barrier + DMA issue), so the
+    // steps go in PAIRS: four stages, one wait + barrier per two K-steps (32 MFMAs), the next pair in flight meanwhile.  An odd
+    // last step computes on a zero-filled stage.
+    issue(0);
+    issue(STAGE);
+    int cur = 0;
+    for (int kt = 0; kt < p.nk; kt += 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this pair has landed (nothing younger is in flight)
+      __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading the previous pair
+      __builtin_amdgcn_sched_barrier(0);
+      const int nxt = cur ^ (2 * STAGE);
+      issue(nxt);                                          // next pair into the two stages the previous pair occupied
+      issue(nxt + STAGE);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      compute(cur + STAGE);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills of the steps beyond the last one have landed
   __builtin_amdgcn_s_barrier();
@@ -324,7 +349,7 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   p.tiles_n = dy_cdiv(d->Cd, bn);
   p.nblk = dy_cdiv(p.M, v5::BM) * p.tiles_n;
   constexpr int RING128 = v5::NSTAGE * (v5::A_BYTES + 128 * 64), EPI128 = dy_epi::row_image_bytes<v5::BM, 128>();
-  constexpr int RING64 = v5::NSTAGE * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
+  constexpr int RING64 = 4 * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
   constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
   static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024, "two blocks per CU");
   static bool configured = false;
