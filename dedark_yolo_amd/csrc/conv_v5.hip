@@ -30,6 +30,16 @@ constexpr unsigned B_ROW_OOB = 0x40000000u;         // weight extent <= 1 GiB: r
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
+__device__ unsigned long long g_stamps[16];       // diagnostics (DY_ABLATE & 32): s_memtime (100 MHz) of wave 0, [0..7] first block, [8..15] a late one
+
+__device__ inline void stamp(int ablate, int nblk, int i) {
+  if ((ablate & 32) && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == (nblk / 8) * 7)) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    g_stamps[(blockIdx.x == 0 ? 0 : 8) + i] = t;
+  }
+}
+
 struct P {
   const char* src;
   const char* w;
@@ -52,6 +62,9 @@ struct P {
   int tiles_n, nblk;
   const char* add_src;           // optional addend view of a data gradient (dy_conv_desc.add_src)
   long add_src_ld;
+  int ablate;                    // DY_ABLATE (make DIAG=1 only): 1 A-operand DMA of taps != 0 out of range (no fetch, zeros land),
+                                 // 2 every A DMA out of range, 4 every B DMA out of range, 8 no MFMA, 16 no fragment reads,
+                                 // 64 taps != 0 issue NO A DMA at all (wait switches to vmcnt(0))
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -69,6 +82,93 @@ __device__ inline long dst_offset(const P& p, long m) {
   return img * p.dst_img + (long)oh * p.dst_row + (long)ow * p.dst_ld;
 }
 
+// Shared tail of the kernels of this file: affine + activation on the accumulators, bf16 / f16 image in LDS, coalesced stores, optional
+// per-channel statistics for BatchNorm (f64 atomics into the tile's replica).
+template <int BN, typename T, int MB>
+__device__ __forceinline__ void epilogue(const P& p, f32x4 (&acc)[MB][4], char* smem, int tid, int lane, int wave, int wm, int wn, long m0,
+                                         int n0, int tile_m) {
+  constexpr int WN = BN / 64, WM = 4 / WN;
+  // ---- epilogue: bf16 image [pixel][channel] (conv_epilogue.h: store_rows) -> 16-byte stores, 256 contiguous bytes per quarter-wave
+  constexpr int PT = dy_epi::row_pitch<BN>();
+  const int cl = lane & 15, g = lane >> 4;
+  float csum[4][4], csq[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c0 = 64 * wn + 16 * j + 4 * g;               // this lane's 4 channels of the block
+    float sc[4], sf[4];
+    bool nok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + c0 + e;
+      nok[e] = n < p.Cd;
+      sc[e] = (nok[e] && p.scale) ? p.scale[n] : 1.f;
+      sf[e] = (nok[e] && p.shift) ? p.shift[n] : 0.f;
+      csum[j][e] = 0.f;
+      csq[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int px = 16 * MB * wm + 16 * i + cl;
+      const bool mok = m0 + px < p.M;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = acc[i][j][e];
+        if (mok && nok[e]) {
+          csum[j][e] += a;
+          csq[j][e] += a * a;
+        }
+        float u = a * sc[e] + sf[e];
+        if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
+        else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
+        v[e] = u;
+      }
+      uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
+      *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
+    }
+  }
+  __syncthreads();
+  stamp(DY_ABLATE_OF(p), p.nblk, 3);
+  dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
+                                [&](long m) { return dst_offset(p, m); }, reinterpret_cast<const T*>(p.add_src), p.add_src_ld);
+  stamp(DY_ABLATE_OF(p), p.nblk, 4);
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = csum[j][e], s2 = csq[j][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {                 // over the 16 pixels on the lanes of a row group
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (cl == 0) {
+          const int col = 64 * wn + 16 * j + 4 * g + e;
+          red[(wm * BN + col) * 2] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.Cd) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += red[(w * BN + tid) * 2];
+          s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
+        atomic_add_f64(st + n, (double)s1);
+        atomic_add_f64(st + p.Cd + n, (double)s2);
+      }
+    }
+  }
+}
+
 // BN = 128: waves 2 (M) x 2 (N), wave tile 128 x 64.  BN = 64 (the 64-channel layers): waves 4 x 1, wave tile 64 x 64.
 template <int BN, typename T = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
@@ -78,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int bid = xcd_remap(blockIdx.x, p.nblk);
+  stamp(DY_ABLATE_OF(p), p.nblk, 0);
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -145,13 +246,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   auto issue = [&](int base) {                 // one stage: 4 + 2 DMA instructions per wave, ONE unconditional load per lane each
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned v = ((a_mask[j] >> s_bit) & 1u) ? a_off[j] + (unsigned)a_koff : A_OOB;
+      unsigned v = ((a_mask[j] >> s_bit) & 1u) ? a_off[j] + (unsigned)a_koff : A_OOB;
+      if (((DY_ABLATE_OF(p) & 1) && (s_th | s_tw)) || (DY_ABLATE_OF(p) & 2)) v = A_OOB;
+      if ((DY_ABLATE_OF(p) & 64) && (s_th | s_tw)) continue;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)v, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + A_BYTES + (wave + 4 * j) * 1024), 16,
-                                               (int)(b_off[j] + b_koff), 0, 0, 0);
+                                               (int)((DY_ABLATE_OF(p) & 4) ? B_ROW_OOB : b_off[j] + b_koff), 0, 0, 0);
     advance();
   };
 
@@ -169,10 +272,22 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 
   auto compute = [&](int base) {               // one staged K-step: 4 + MB fragment reads, MB x 4 MFMAs
     u32x4 bfr[NB], afr[MB];
+    if (DY_ABLATE_OF(p) & 16) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + base + b_rd + 1024 * j);
+      for (int j = 0; j < 4; ++j) bfr[j] = u32x4{0x3f803f80u + (unsigned)base, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 #pragma unroll
-    for (int i = 0; i < MB; ++i) afr[i] = *reinterpret_cast<const u32x4*>(smem + base + a_rd + 1024 * i);
+      for (int i = 0; i < MB; ++i) afr[i] = u32x4{0x3f803f80u, 0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3f803f80u};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + base + b_rd + 1024 * j);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) afr[i] = *reinterpret_cast<const u32x4*>(smem + base + a_rd + 1024 * i);
+    }
+    if (DY_ABLATE_OF(p) & 8) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i][0][0] += __builtin_bit_cast(float, afr[i][0] ^ bfr[i & 3][1]);
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -182,11 +297,14 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
         acc[i][j] = mfma_16x16x32<T>(bfr[j], afr[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
   };
+  stamp(DY_ABLATE_OF(p), p.nblk, 1);
   if constexpr (BN >= 128) {
     issue(0);
     issue(STAGE);
     int cur = 0, fill = 2 * STAGE;
     for (int kt = 0; kt < p.nk; ++kt) {
+      if (DY_ABLATE_OF(p) & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + B_LD) : "memory");    // everything but the youngest stage: K-step kt has landed
       __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading K-step kt - 1
       __builtin_amdgcn_sched_barrier(0);
@@ -220,87 +338,230 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills of the steps beyond the last one have landed
   __builtin_amdgcn_s_barrier();
+  stamp(DY_ABLATE_OF(p), p.nblk, 2);
 
-  // ---- epilogue: bf16 image [pixel][channel] (conv_epilogue.h: store_rows) -> 16-byte stores, 256 contiguous bytes per quarter-wave
-  constexpr int PT = dy_epi::row_pitch<BN>();
-  const int cl = lane & 15, g = lane >> 4;
-  float csum[4][4], csq[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c0 = 64 * wn + 16 * j + 4 * g;               // this lane's 4 channels of the block
-    float sc[4], sf[4];
-    bool nok[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = n0 + c0 + e;
-      nok[e] = n < p.Cd;
-      sc[e] = (nok[e] && p.scale) ? p.scale[n] : 1.f;
-      sf[e] = (nok[e] && p.shift) ? p.shift[n] : 0.f;
-      csum[j][e] = 0.f;
-      csq[j][e] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      const int px = 16 * MB * wm + 16 * i + cl;
-      const bool mok = m0 + px < p.M;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = acc[i][j][e];
-        if (mok && nok[e]) {
-          csum[j][e] += a;
-          csq[j][e] += a * a;
-        }
-        float u = a * sc[e] + sf[e];
-        if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
-        else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
-        v[e] = u;
-      }
-      uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
-      *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
-    }
-  }
-  __syncthreads();
-  dy_epi::store_rows<BM, BN, 4>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
-                                [&](long m) { return dst_offset(p, m); }, reinterpret_cast<const T*>(p.add_src), p.add_src_ld);
-  if (p.stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s1 = csum[j][e], s2 = csq[j][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {                 // over the 16 pixels on the lanes of a row group
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
-        if (cl == 0) {
-          const int col = 64 * wn + 16 * j + 4 * g + e;
-          red[(wm * BN + col) * 2] = s1;
-          red[(wm * BN + col) * 2 + 1] = s2;
-        }
-      }
-    __syncthreads();
-    if (tid < BN) {
-      const int n = n0 + tid;
-      if (n < p.Cd) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          s1 += red[(w * BN + tid) * 2];
-          s2 += red[(w * BN + tid) * 2 + 1];
-        }
-        double* st = p.stats + (long)(tile_m % DY_STATS_REPLICAS) * 2 * p.Cd;
-        atomic_add_f64(st + n, (double)s1);
-        atomic_add_f64(st + p.Cd + n, (double)s2);
-      }
-    }
-  }
+  epilogue<BN, T, MB>(p, acc, smem, tid, lane, wave, wm, wn, m0, n0, tile_m);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(DY_ABLATE_OF(p), p.nblk, 5);
 }
 
+// ---- 3x3 / stride 1 / pad 1 ("same") layers: activation BAND kernel.
+// tools/conv_bench stamps (DY_ABLATE=32, make DIAG=1) showed what bounds conv_kernel's K loop: not the MFMA pipe, the LDS reads or the
+// fetches, but the LDS-DMA round trip.  A stage needs ~3,000 cycles from issue to landed even when every lane is out of range, ~4,600
+// under load, and with two of three stages in flight a K-step cannot take less than half of that: 2,300 cycles per step against
+// 1,024 cycles of MFMA work of the CU's two blocks.  Bytes in flight are bounded by LDS, so the way to more K-steps in flight is fewer
+// bytes per step: the three kw taps of one kernel row read the SAME pixels shifted by one, so a band of 258 (272) consecutive
+// flattened pixels x 32 channels serves three K-steps (17 KiB instead of 3 x 16 KiB), the weight tiles (8 / 4 KiB per step) get their
+// own deeper ring, and the DMA addresses need no (n, h, w) arithmetic at all: band row i is pixel m0 - 1 + i + dh * W of the flattened
+// [N*H*W] source, anything outside the buffer lands as zeros.  What the flattening gets wrong -- taps that cross the left / right /
+// top / bottom border of an image read a real neighbour pixel -- is repaired at the fragment read: a lane whose (pixel, tap) is
+// padding reads a zero row instead (one v_cndmask on the address per fragment, masks precomputed per lane: 9 taps x MB pixels).
+//   BN = 128: 2 bands + 4 weight tiles (66 KiB), weights 3 steps ahead; BN = 64: 3 bands + 7 weight tiles (79 KiB), 6 steps ahead.
+//   Step t = 3g + tw issues [band g + NBAND - 1 if tw == 0] + weight tile t + DB, DB = 3 (NBAND - 1); its wait leaves exactly the
+//   issues of steps t - DB + 1 .. t - 1 in flight (counted vmcnt, a constant per tw).
+constexpr int BAND_BYTES = 17 * 1024;               // 272 rows of 64 bytes
+
+template <int BN, typename T = bf16_t>
+__global__ __launch_bounds__(256, 2) void band_kernel(const P p) {
+  constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, B_LD = BN / 64, B_BYTES = BN * 64;
+  constexpr int NBAND = BN == 64 ? 3 : 2, DB = 3 * (NBAND - 1), NBBUF = DB + 1;
+  constexpr int OFF_B = NBAND * BAND_BYTES, OFF_ZERO = OFF_B + NBBUF * B_BYTES;
+  constexpr int N0 = (DB - 1) * B_LD + 5 * (NBAND - 2), N1 = (DB - 1) * B_LD + 5 * (NBAND - 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  stamp(DY_ABLATE_OF(p), p.nblk, 0);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  if (tid < 16) reinterpret_cast<unsigned*>(smem + OFF_ZERO)[tid] = 0u;      // the zero row (visible after the first barrier)
+
+  // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills band rows 16*idx .. +15 (j < 4) / weight rows (j < B_LD); the 17th
+  // band block (rows 256 .. 271, of which 256 and 257 are read) is filled by all four waves, 16 lanes each
+  const int lrow = lane >> 2, slot = lane & 3;
+  const int chunk = slot ^ ((lane & 32) ? 3 : 0);
+  const bool tail_lane = (lane >> 4) == wave;
+  unsigned a_off[5], b_off[B_LD];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int brow = j < 4 ? 16 * (wave + 4 * j) + lrow : 256 + lrow;
+    a_off[j] = (unsigned)((m0 - 1 + brow) * p.src_ld * 2 + chunk * 16);     // mod 2^32: a negative pixel index wraps out of range
+  }
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int n = n0 + 16 * (wave + 4 * j) + lrow;
+    b_off[j] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
+  }
+  const int ng = p.nk / 3;                     // bands: (32-channel chunk, kernel row)
+  int ga_n = 0, ga_th = 0, ga_ci = 0;          // band being issued (wave-uniform)
+  auto issue_band = [&](int base) {
+    const bool live = ga_n < ng && !(DY_ABLATE_OF(p) & 2);
+    const unsigned koff = (unsigned)((p.dh0 + p.dhs * ga_th) * p.Ws * (int)p.src_ld * 2 + ga_ci * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16,
+                                               (int)(live ? a_off[j] + koff : A_OOB), 0, 0, 0);
+    if (tail_lane)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + 16 * 1024), 16, (int)(live ? a_off[4] + koff : A_OOB), 0, 0, 0);
+    ++ga_n;
+    if (++ga_th == 3) { ga_th = 0; ga_ci += BK; }
+  };
+  int kb = 0, kb_tp = 0, kb_ci = 0;            // weight tile being issued: K order = chunk, kernel row, kernel column
+  auto issue_b = [&](int base) {
+    const unsigned koff = (kb < p.nk && !(DY_ABLATE_OF(p) & 4)) ? (unsigned)(((long)kb_tp * p.Cs + kb_ci) * 2) : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)(b_off[j] + koff), 0, 0, 0);
+    ++kb;
+    if (++kb_tp == 9) { kb_tp = 0; kb_ci += BK; }
+  };
+
+  // ---- fragment read addresses (16x16x32 operand: lane = row l&15, chunk l>>4); band row of output pixel r for column tap tw:
+  // r + 1 + dw(tw)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int r0 = 16 * MB * wm + fr;
+  int a_rd[3];
+#pragma unroll
+  for (int tw = 0; tw < 3; ++tw) {
+    const int brow = r0 + 1 + p.dw0 + p.dws * tw;
+    a_rd[tw] = brow * 64 + ((fq ^ ((brow & 8) ? 3 : 0)) * 16);             // + 1024 * m-block
+  }
+  const int b_rd = (64 * wn + fr) * 64 + ((fq ^ ((fr & 8) ? 3 : 0)) * 16); // + 1024 * n-block
+  // padding masks: bit 8*tw + i of tm[th] = tap (th, tw) of this lane's pixel of m-block i lies inside the image
+  unsigned tm[3] = {0u, 0u, 0u};
+  {
+    const long m = m0 + r0;
+    const unsigned mm = m < p.M ? (unsigned)m : 0u;
+    const unsigned HWd = (unsigned)(p.Hd * p.Wd);
+    const unsigned img = mm / HWd;
+    const int rem = (int)(mm - img * HWd);
+    int h = (int)((unsigned)rem / (unsigned)p.Wd), w = rem - h * p.Wd;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const bool ok = m + 16 * i < p.M;
+#pragma unroll
+      for (int th = 0; th < 3; ++th) {
+        const bool hv = (unsigned)(h + p.dh0 + p.dhs * th) < (unsigned)p.Hs;
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+          const bool wv = (unsigned)(w + p.dw0 + p.dws * tw) < (unsigned)p.Ws;
+          if (ok && hv && wv) tm[th] |= 1u << (8 * tw + i);
+        }
+      }
+      w += 16;                                 // Wd >= 16 (launcher): at most one row wrap
+      if (w >= p.Wd) {
+        w -= p.Wd;
+        if (++h == p.Hd) h = 0;
+      }
+    }
+  }
+
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int band_base, int b_base, unsigned bits, int ard) {
+    u32x4 bfr[4], afr[MB];
+    const int av = band_base + ard;
+    if (DY_ABLATE_OF(p) & 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = u32x4{0x3f803f80u + (unsigned)b_base, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+      for (int i = 0; i < MB; ++i) afr[i] = u32x4{0x3f803f80u, 0x3f803f80u + (bits & 1u), 0x3f803f80u, 0x3f803f80u};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(smem + b_base + b_rd + 1024 * j);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int sel = ((bits >> i) & 1u) ? av : OFF_ZERO - 1024 * i;
+        afr[i] = *reinterpret_cast<const u32x4*>(smem + sel + 1024 * i);
+      }
+    }
+    if (DY_ABLATE_OF(p) & 8) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i][0][0] += __builtin_bit_cast(float, afr[i][0] ^ bfr[i & 3][1]);
+      return;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32<T>(bfr[j], afr[i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  stamp(DY_ABLATE_OF(p), p.nblk, 1);
+
+  // virtual steps -DB .. -1: bands 0 .. NBAND-2, weight tiles 0 .. DB-1
+  int band_fill = 0, b_fill = 0;
+#pragma unroll
+  for (int s = 0; s < DB; ++s) {
+    if (s % 3 == 0) {
+      issue_band(band_fill);
+      band_fill += BAND_BYTES;
+    }
+    issue_b(OFF_B + b_fill);
+    b_fill += B_BYTES;
+  }
+  int band_cur = 0, b_cur = 0, th = 0;
+  auto next_b = [&]() {
+    b_cur = b_cur == DB * B_BYTES ? 0 : b_cur + B_BYTES;
+    b_fill = b_fill == DB * B_BYTES ? 0 : b_fill + B_BYTES;
+  };
+  for (int g = 0; g < ng; ++g) {
+    const unsigned tmc = th == 0 ? tm[0] : (th == 1 ? tm[1] : tm[2]);
+    // ---- tw = 0: also refills the band slot the previous band group left
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_band(band_fill);
+    issue_b(OFF_B + b_fill);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(band_cur, OFF_B + b_cur, tmc, a_rd[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    next_b();
+    // ---- tw = 1
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(OFF_B + b_fill);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(band_cur, OFF_B + b_cur, tmc >> 8, a_rd[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    next_b();
+    // ---- tw = 2
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(OFF_B + b_fill);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(band_cur, OFF_B + b_cur, tmc >> 16, a_rd[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    next_b();
+    band_cur = band_cur == (NBAND - 1) * BAND_BYTES ? 0 : band_cur + BAND_BYTES;
+    band_fill = band_fill == (NBAND - 1) * BAND_BYTES ? 0 : band_fill + BAND_BYTES;
+    th = th == 2 ? 0 : th + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills beyond the last step have landed
+  __builtin_amdgcn_s_barrier();
+  stamp(DY_ABLATE_OF(p), p.nblk, 2);
+  epilogue<BN, T, MB>(p, acc, smem, tid, lane, wave, wm, wn, m0, n0, tile_m);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(DY_ABLATE_OF(p), p.nblk, 5);
+}
+
+
 }  // namespace v5
+
+extern "C" int dy_debug_conv5_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(v5::g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
 
 bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
   static const bool off = dy_env("DY_NO_CONV_V5") != nullptr;
@@ -343,6 +604,8 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   p.M = (long)d->N * d->Hd * d->Wd;
   p.add_src = mode == 1 ? (const char*)d->add_src : nullptr; p.add_src_ld = d->add_src_ld;
   p.nk = d->KH * d->KW * d->Cs / v5::BK;
+  static const int ablate = dy_env("DY_ABLATE") ? atoi(dy_env("DY_ABLATE")) : 0;
+  p.ablate = ablate;
   p.dst_row = d->dst_row_stride;
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
   const int bn = d->Cd <= 64 ? 64 : 128;
@@ -351,13 +614,23 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   constexpr int RING128 = v5::NSTAGE * (v5::A_BYTES + 128 * 64), EPI128 = dy_epi::row_image_bytes<v5::BM, 128>();
   constexpr int RING64 = 4 * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
   constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
-  static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024, "two blocks per CU");
+  constexpr int BAND128 = 2 * v5::BAND_BYTES + 4 * 128 * 64 + 64, BAND64 = 3 * v5::BAND_BYTES + 7 * 64 * 64 + 64;
+  constexpr int SB128 = BAND128 > EPI128 ? BAND128 : EPI128, SB64 = BAND64 > EPI64 ? BAND64 : EPI64;
+  static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024 && 2 * SB128 <= 160 * 1024 && 2 * SB64 <= 160 * 1024, "two blocks per CU");
+  // 3x3 / stride 1 / pad 1 on an unchanged pixel grid: the band kernel
+  static const bool no_band = dy_env("DY_NO_CONV_BAND") != nullptr;
+  const bool band = !no_band && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->KHf <= 0 && d->Hs == d->Hd &&
+                    d->Ws == d->Wd && d->Ws >= 16;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<128, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64);
     if (e != hipSuccess) {
       dy_set_error("conv_v5: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
@@ -365,7 +638,15 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     configured = true;
   }
   const bool f16 = d->dtype == DY_F16;
-  if (bn == 128) {
+  if (band && bn == 128) {
+    dy_note_kernel("v5::band_kernel<128>");
+    if (f16) v5::band_kernel<128, f16_t><<<p.nblk, 256, SB128, (hipStream_t)stream>>>(p);
+    else v5::band_kernel<128, bf16_t><<<p.nblk, 256, SB128, (hipStream_t)stream>>>(p);
+  } else if (band) {
+    dy_note_kernel("v5::band_kernel<64>");
+    if (f16) v5::band_kernel<64, f16_t><<<p.nblk, 256, SB64, (hipStream_t)stream>>>(p);
+    else v5::band_kernel<64, bf16_t><<<p.nblk, 256, SB64, (hipStream_t)stream>>>(p);
+  } else if (bn == 128) {
     dy_note_kernel("v5::conv_kernel<128>");
     if (f16) v5::conv_kernel<128, f16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
     else v5::conv_kernel<128, bf16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);

@@ -10,6 +10,7 @@
 #include "../include/dedark_yolo.h"
 extern "C" int dy_debug_conv_stamps(unsigned long long* out);
 extern "C" int dy_debug_conv3_stamps(unsigned long long* out);
+extern "C" int dy_debug_conv5_stamps(unsigned long long* out);
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -98,7 +99,18 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&ms[which], e0, e1));
       ms[which] /= iters;
     }
-    if (getenv("DY_ABLATE") && (atoi(getenv("DY_ABLATE")) & 32)) {
+    if (getenv("DY_ABLATE") && (atoi(getenv("DY_ABLATE")) & 32) && getenv("CB_V5")) {       // conv_v5 stamps: first block and a late one
+      unsigned long long t[16];
+      for (int which = 0; which < 2; ++which) {
+        CK(hipDeviceSynchronize());
+        if (which == 0) dy_conv2d_fwd(&f, st); else dy_conv2d_dgrad(&g, st);
+        CK(hipDeviceSynchronize());
+        dy_debug_conv5_stamps(t);
+        for (int b = 0; b < 16; b += 8)
+          printf("   %s %s block (10 ns ticks): start +%llu | prologue %llu | K loop %llu | lds image %llu | stores %llu | stats %llu | total %llu\n", which ? "dgrad" : "fwd",
+                 b ? "late" : "first", t[b] - t[0], t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], t[b + 5] - t[b + 4], t[b + 5] - t[b]);
+      }
+    } else if (getenv("DY_ABLATE") && (atoi(getenv("DY_ABLATE")) & 32)) {
       unsigned long long t[16];
       CK(hipDeviceSynchronize());
       dy_conv2d_fwd(&f, st);

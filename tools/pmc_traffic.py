@@ -20,7 +20,7 @@ CLASSES = {
     "dy_conv2d_wgrad": [r"wg2::wgrad_kernel", r"wg2::reduce_kernel", r"wg3::wgrad_kernel", r"wg3::reduce_kernel", r"wg4::wgrad_kernel",
                         r"wg4::reduce_kernel", r"conv_wgrad_kernel", r"wgrad_reduce_kernel", r"dense_wgrad_kernel"],
     # forward and input-gradient convs run the same kernels (a dgrad is a conv over the transposed, flipped weights)
-    "dy_conv2d_fwd+dy_conv2d_dgrad": [r"v4::conv_kernel", r"v5::conv_kernel", r"v3::conv3x3_kernel", r"v2::conv_kernel", r"conv_igemm_kernel",
+    "dy_conv2d_fwd+dy_conv2d_dgrad": [r"v4::conv_kernel", r"v5::conv_kernel", r"v5::band_kernel", r"v3::conv3x3_kernel", r"v2::conv_kernel", r"conv_igemm_kernel",
                                       r"conv_thin_kernel", r"dgrad1x1_thin_kernel", r"dgrad3x3s2_small_kernel", r"conv_dense_kernel",
                                       r"conv_generic_kernel", r"conv_small_kernel"],
     "dy_bn_act_bwd_reduce": [r"bn_act_bwd_reduce_kernel"],
