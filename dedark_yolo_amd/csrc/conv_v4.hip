@@ -340,45 +340,47 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   // ---- epilogue: bf16 image [pixel][channel] (conv_epilogue.h: store_rows) -> 16-byte stores, 256 contiguous bytes per quarter-wave
   constexpr int PT = dy_epi::row_pitch<BN>();
   const int cl = lane & 15, g = lane >> 4;
-  float csum[2][2][4], csq[2][2][4];
+  const bool plain = !p.scale && !p.shift && p.act == DY_ACT_NONE;   // raw output: training forward (BatchNorm follows), data gradients
 #pragma unroll
   for (int bh = 0; bh < 2; ++bh)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c0 = 128 * bh + 32 * wc + 16 * j + 4 * g;       // this lane's 4 channels of the block
-      float sc[4], sf[4];
-      bool nok[4];
+      if (plain) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + c0 + e;
-        nok[e] = n < p.Cd;
-        sc[e] = (nok[e] && p.scale) ? p.scale[n] : 1.f;
-        sf[e] = (nok[e] && p.shift) ? p.shift[n] : 0.f;
-        csum[bh][j][e] = 0.f;
-        csq[bh][j][e] = 0.f;
-      }
+        for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
-      for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int px = 128 * ah + 64 * wr + 16 * i + cl;
-          const bool mok = m0 + px < p.M;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = acc[ah][bh][i][j][e];
-            if (mok && nok[e]) {
-              csum[bh][j][e] += a;
-              csq[bh][j][e] += a * a;
-            }
-            float u = a * sc[e] + sf[e];
-            if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
-            else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
-            v[e] = u;
+          for (int i = 0; i < 4; ++i) {
+            const int px = 128 * ah + 64 * wr + 16 * i + cl;
+            uint2 w2 = {dy_epi::pack2<T>(acc[ah][bh][i][j][0], acc[ah][bh][i][j][1]), dy_epi::pack2<T>(acc[ah][bh][i][j][2], acc[ah][bh][i][j][3])};
+            *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
           }
-          uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
-          *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
+      } else {
+        float sc[4], sf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + c0 + e;
+          const bool nok = n < p.Cd;
+          sc[e] = (nok && p.scale) ? p.scale[n] : 1.f;
+          sf[e] = (nok && p.shift) ? p.shift[n] : 0.f;
         }
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int px = 128 * ah + 64 * wr + 16 * i + cl;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float u = acc[ah][bh][i][j][e] * sc[e] + sf[e];
+              if (p.act == DY_ACT_SILU) u = u * dy_sigmoid(u);
+              else if (p.act == DY_ACT_LEAKY) u = u > 0.f ? u : 0.1f * u;
+              v[e] = u;
+            }
+            uint2 w2 = {dy_epi::pack2<T>(v[0], v[1]), dy_epi::pack2<T>(v[2], v[3])};
+            *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
+          }
+      }
     }
   __syncthreads();
   if (!(ABL & 64))
@@ -393,12 +395,18 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float s1 = csum[bh][j][e], s2 = csq[bh][j][e];
+          // rows beyond M and channels beyond Cd were fed zeros by the DMA: their accumulators are exactly 0, no predicate needed
+          float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {             // over the 16 pixels on the lanes of a row group
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-          }
+          for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float a = acc[ah][bh][i][j][e];
+              s1 += a;
+              s2 += a * a;
+            }
+          s1 = row16_sum(s1);                                  // over the 16 pixels on the lanes of a row group
+          s2 = row16_sum(s2);
           if (cl == 0) {
             const int col = 128 * bh + 32 * wc + 16 * j + 4 * g + e;
             red[(wr * BN + col) * 2] = s1;

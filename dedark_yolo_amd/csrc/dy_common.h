@@ -180,6 +180,15 @@ __host__ __device__ inline float dy_dact(int act, float u) {
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------------------
+// sum over each aligned group of 16 lanes (a DPP row), result in every lane of the group: four v_add_f32 with a DPP operand
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips through LDS
+__device__ inline float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

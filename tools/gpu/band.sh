@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_conv_kernels.py tests/test_gpu_parity.py tests/test_gpu_lowprec.py -x -q -m gpu 2>&1 | tail -5
-timeout -k 10 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
-timeout -k 10 600 python bench.py --model yolov8n-lowlight.yaml --batch 32 --steps 60 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-250
+out=gpurun_out/band3.txt; : > $out
+CB_CHECK=1 CB_ONLY="3x3" timeout -k 10 600 tools/bin/conv_bench 30 64 2>&1 | grep -v "^$" >> $out || echo "rc=$?" >> $out
+cat $out
+timeout -k 10 900 python -m pytest tests/test_gpu_conv_kernels.py -x -q -m gpu 2>&1 | tail -3
