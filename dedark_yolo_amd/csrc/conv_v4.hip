@@ -100,26 +100,23 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   const int chunk = slot ^ ((4 * wave + (lane >> 4)) & 7);      // logical 16-byte chunk of the row this lane fetches
   unsigned a_off[4], a_mask[4], b_off[4];                        // index = 2 * half + j
   {
-    const long HWd = (long)p.Hd * p.Wd;
+    const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
-      const long m = m0 + r;
-      const bool ok = m < p.M;
-      const unsigned mm = ok ? (unsigned)m : 0u;           // M < 2^31 (checked by the launcher): 32-bit divisions
-      const int img = (int)(mm / (unsigned)HWd);
-      const int rem = (int)(mm - (unsigned)img * (unsigned)HWd);
-      const int oh = (int)((unsigned)rem / (unsigned)p.Wd), ow = rem - oh * p.Wd;
+      const bool ok = m0 + r < p.M;
+      int img, oh, ow;
+      walk.at(r, img, oh, ow);
       const int sh0 = oh * p.stride, sw0 = ow * p.stride;
       a_off[i] = (unsigned)((((long)img * p.Hs + sh0) * p.Ws + sw0) * p.src_ld * 2 + chunk * 16);
-      unsigned mk = 0;
-      int bit = 0;
+      unsigned wb = 0, mk = 0;                             // bit th * KW + tw: window tap (th, tw) of this row lies inside the image
+      for (int tw = 0; tw < p.KW; ++tw) {
+        const int sw = sw0 + p.dw0 + p.dws * tw;
+        if (sw >= 0 && sw < p.Ws) wb |= 1u << tw;
+      }
       for (int th = 0; th < p.KH; ++th) {
         const int sh = sh0 + p.dh0 + p.dhs * th;
-        for (int tw = 0; tw < p.KW; ++tw, ++bit) {
-          const int sw = sw0 + p.dw0 + p.dws * tw;
-          if (ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws) mk |= 1u << bit;
-        }
+        if (ok && sh >= 0 && sh < p.Hs) mk |= wb << (th * p.KW);
       }
       a_mask[i] = mk;
       const int n = n0 + 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;

@@ -196,26 +196,23 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   const int chunk = slot ^ ((lane & 32) ? 3 : 0);          // logical 16-byte chunk (8 channels of the 32-deep step) this lane fetches
   unsigned a_off[4], a_mask[4], b_off[B_LD];
   {
-    const unsigned HWd = (unsigned)(p.Hd * p.Wd);
+    const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 16 * (wave + 4 * j) + lrow;
-      const long m = m0 + r;
-      const bool ok = m < p.M;
-      const unsigned mm = ok ? (unsigned)m : 0u;           // M < 2^31 (checked by the launcher): 32-bit divisions
-      const int img = (int)(mm / HWd);
-      const int rem = (int)(mm - (unsigned)img * HWd);
-      const int oh = (int)((unsigned)rem / (unsigned)p.Wd), ow = rem - oh * p.Wd;
+      const bool ok = m0 + r < p.M;
+      int img, oh, ow;
+      walk.at(r, img, oh, ow);
       const int sh0 = oh * p.stride, sw0 = ow * p.stride;
       a_off[j] = (unsigned)((((long)img * p.Hs + sh0) * p.Ws + sw0) * p.src_ld * 2 + chunk * 16);
-      unsigned mk = 0;
-      int bit = 0;
+      unsigned wb = 0, mk = 0;                             // bit th * KW + tw: window tap (th, tw) of this row lies inside the image
+      for (int tw = 0; tw < p.KW; ++tw) {
+        const int sw = sw0 + p.dw0 + p.dws * tw;
+        if (sw >= 0 && sw < p.Ws) wb |= 1u << tw;
+      }
       for (int th = 0; th < p.KH; ++th) {
         const int sh = sh0 + p.dh0 + p.dhs * th;
-        for (int tw = 0; tw < p.KW; ++tw, ++bit) {
-          const int sw = sw0 + p.dw0 + p.dws * tw;
-          if (ok && sh >= 0 && sh < p.Hs && sw >= 0 && sw < p.Ws) mk |= 1u << bit;
-        }
+        if (ok && sh >= 0 && sh < p.Hs) mk |= wb << (th * p.KW);
       }
       a_mask[j] = mk;
     }
@@ -441,11 +438,8 @@ __global__ __launch_bounds__(256, 2) void band_kernel(const P p) {
   unsigned tm[3] = {0u, 0u, 0u};
   {
     const long m = m0 + r0;
-    const unsigned mm = m < p.M ? (unsigned)m : 0u;
-    const unsigned HWd = (unsigned)(p.Hd * p.Wd);
-    const unsigned img = mm / HWd;
-    const int rem = (int)(mm - img * HWd);
-    int h = (int)((unsigned)rem / (unsigned)p.Wd), w = rem - h * p.Wd;
+    int img, h, w;
+    DyTileWalk(m0, p.Hd, p.Wd).at(r0, img, h, w);
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const bool ok = m + 16 * i < p.M;

@@ -179,6 +179,37 @@ __host__ __device__ inline float dy_dact(int act, float u) {
   return 1.0f;
 }
 
+// ---- output pixel -> (image, row, column) for the rows of one tile ---------------------------------------------------------------
+// The integer division pair is done once, on the wave-uniform first pixel of the tile; a lane's row offset r (< 65,536) is folded in
+// with float reciprocals: floor((x + 0.5) * (1 / d)) is exact for x < 2^16 (the true value is at least 0.5 / d away from an
+// integer, the float error is below (x + 0.5) / d * 2^-22).  Four 32-bit divisions per lane cost more than the rest of a conv tile's
+// address set-up together.
+struct DyTileWalk {
+  int img0, oh0, ow0, Hd, Wd;
+  float inv_h, inv_w;
+  __device__ inline DyTileWalk(long m0, int Hd_, int Wd_) : Hd(Hd_), Wd(Wd_) {
+    const unsigned HWd = (unsigned)(Hd_ * Wd_);
+    const unsigned mm = (unsigned)m0;                    // m0 < 2^31 (launchers)
+    const unsigned img = mm / HWd;
+    const unsigned rem = mm - img * HWd;
+    const unsigned oh = rem / (unsigned)Wd_;
+    img0 = (int)img;
+    oh0 = (int)oh;
+    ow0 = (int)(rem - oh * (unsigned)Wd_);
+    inv_h = 1.0f / (float)Hd_;
+    inv_w = 1.0f / (float)Wd_;
+  }
+  __device__ inline void at(int r, int& img, int& oh, int& ow) const {
+    const int x = ow0 + r;
+    const int q = (int)(((float)x + 0.5f) * inv_w);
+    ow = x - q * Wd;
+    const int y = oh0 + q;
+    const int q2 = (int)(((float)y + 0.5f) * inv_h);
+    oh = y - q2 * Hd;
+    img = img0 + q2;
+  }
+};
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------------------
 // sum over each aligned group of 16 lanes (a DPP row), result in every lane of the group: four v_add_f32 with a DPP operand
 // (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips through LDS
