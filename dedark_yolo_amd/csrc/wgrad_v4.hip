@@ -71,6 +71,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
   const int split = bid / p.tiles, tile = bid - split * p.tiles;
   const int tile_p = tile / p.tiles_q, tile_q = tile - tile_p * p.tiles_q;
   const int kp0 = tile_p * BP, q0 = tile_q * BQ;
+  // the upper 128 output channels of the tile do not exist (Cout <= 128 layers): their dz unit is still issued (out of range: zeros,
+  // no fetch -- the vmcnt bookkeeping stays the same) but neither read nor multiplied nor stored
+  const bool has_b1 = q0 + 128 < p.Cout;
+  const bool has_a1 = kp0 + 128 < p.Ktot;                   // likewise the upper 128 k' of the last k' tile (K = 1152: 4.5 tiles)
   const long m_begin = (long)split * p.chunk;
   const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
   const int nk = m_begin < m_end ? (int)((m_end - m_begin + BKP - 1) / BKP) : 0;
@@ -286,29 +290,31 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
     mma(0, 0);
     __builtin_amdgcn_s_barrier();
     // P2: B unit 1; refill B unit 0 two K-steps ahead; the rows move on by 64 pixels
-    WG4_READ_B(OFF_B1, 1);
+    if (has_b1) WG4_READ_B(OFF_B1, 1);
     __builtin_amdgcn_sched_barrier(0);
     stage_b(b, 0);
     advance_rows();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(0, 1);
+    if (has_b1) mma(0, 1);
     __builtin_amdgcn_s_barrier();
     // P3: A unit 1; refill A unit 0
-    WG4_READ_A2(OFF_A1, 0);
-    WG4_READ_A2(OFF_A1, 2);
+    if (has_a1) {
+      WG4_READ_A2(OFF_A1, 0);
+      WG4_READ_A2(OFF_A1, 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     stage_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(1, 1);
+    if (has_b1 && has_a1) mma(1, 1);
     __builtin_amdgcn_s_barrier();
     // P4: refill B unit 1; everything but the three youngest units has landed
     stage_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    mma(1, 0);
+    if (has_a1) mma(1, 0);
     __builtin_amdgcn_s_barrier();
     const int delta = cur ? -BUF : BUF;
 #pragma unroll
@@ -329,11 +335,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
   for (int bh = 0; bh < 2; ++bh)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (bh == 1 && !has_b1) continue;                     // (the reduce kernel never reads channels >= Cout)
       const int co = 128 * bh + 32 * wc + 16 * j + cl;
 #pragma unroll
       for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (ah == 1 && !has_a1) continue;
           const int k = 128 * ah + 64 * wr + 16 * i + 4 * g;
           *reinterpret_cast<f32x4*>(out + (long)co * BP + k) = acc[ah][bh][i][j];
         }

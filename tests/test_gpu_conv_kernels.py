@@ -100,12 +100,12 @@ ROUTED = [
     ((31, 192, 232, 41, 43, 3, 1, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # ragged pixels / channels
     ((13, 512, 256, 80, 80, 1, 1, 0), ("v4::conv_kernel", "v5::conv_kernel<128>", "wg4::wgrad_kernel")),        # 1x1: K = 512 / K = 256
     ((20, 256, 512, 80, 80, 3, 2, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # stride 2 (dgrad: parity classes)
-    ((24, 128, 128, 80, 80, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", None)),                   # 3x3 s1 p1: activation band
+    ((24, 128, 128, 80, 80, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", "wg3::wgrad_kernel<128>")), # 3x3 s1 p1: activation band; band weight gradient
     ((128, 128, 128, 33, 16, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", None)),                 # narrowest image the band takes
     ((120, 64, 64, 33, 17, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", None)),                     # ragged: a tile spans 15 image rows
     ((20, 128, 128, 57, 61, 3, 1, 2, 2), ("v5::conv_kernel<128>", "v5::conv_kernel<128>", None)),               # dilated, ragged
     ((20, 96, 224, 57, 61, 3, 1, 1), ("v5::band_kernel<128>", None, "wg4::wgrad_kernel")),                      # 96 = 3 x 32 source channels, ragged
-    ((12, 64, 64, 160, 160, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", None)),
+    ((12, 64, 64, 160, 160, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", "wg3::wgrad_kernel<64>")),
     ((44, 256, 64, 40, 40, 3, 1, 1), ("v5::band_kernel<64>", None, None)),                                      # Detect stem: 8 channel chunks
     ((8, 320, 128, 160, 160, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),
     ((6, 64, 256, 63, 65, 5, 1, 2), (None, None, "wg4::wgrad_kernel")),                                         # 5x5 taps in the mixed-radix walk
