@@ -215,10 +215,13 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   p.co_stride = 0;
   p.part = scratch;
   const int ny = Cout_pad / CO;
-  // about 512 blocks, whole rows of one image each, and the slabs must fit the scratch buffer
+  // ONE round of blocks over the 256 CUs (1 block per CU: the row buffers take 131 KB), whole rows of one image each: every block
+  // parks a 295 / 147 KB slab, so a second round costs more in slab traffic than its finer tail saves (B = 64: 128->128 at 80x80
+  // 203 -> 159 us, 64->64 at 160x160 183 -> 170 us with 256 instead of 512 blocks); and the slabs must fit the scratch buffer
   const long slab = (long)9 * Cin_pad * CO;
   const long maxblk = scratch_elems / (slab * ny);
-  int nseg = (int)((512 / ny + N - 1) / N);
+  static const int target_blocks = dy_env("DY_WG3_BLOCKS") ? atoi(dy_env("DY_WG3_BLOCKS")) : 256;
+  int nseg = target_blocks / (N * ny);
   if ((long)N * nseg > maxblk) nseg = (int)(maxblk / N);
   if (nseg < 1) nseg = 1;
   if (nseg > Hi) nseg = Hi;
