@@ -172,15 +172,13 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 32 ? 6 : 1)) void conv_igemm_kerne
   const char* a_base[AR];
   int a_h[AR], a_w[AR];
   bool a_ok[AR];
-  const long HWd = (long)p.Hd * p.Wd;
+  const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    long m = m0 + r0 + 32 * i;
-    a_ok[i] = m < p.M;
-    long mm = a_ok[i] ? m : 0;
-    int img = (int)(mm / HWd);
-    int rem = (int)(mm - (long)img * HWd);
-    int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    const int r = r0 + 32 * i;
+    a_ok[i] = m0 + r < p.M;
+    int img, oh, ow;
+    walk.at(r, img, oh, ow);
     a_base[i] = p.src + (long)img * p.Hs * p.Ws * p.src_ld * (long)sizeof(T);
     if (MODE == 0) {
       a_h[i] = oh * p.stride - p.pad;
@@ -411,18 +409,16 @@ __global__ __launch_bounds__(NTHREADS, (CS16 == 3 ? 3 : 4)) void conv_thin_kerne
 
   // ---- this lane's pixel of each of the wave's two tiles
   const int row = lane & 31, half = lane >> 5;
-  const long HWd = (long)p.Hd * p.Wd;
+  const DyTileWalk walk(m0, p.Hd, p.Wd);
   const char* a_base[2];
   int a_h[2], a_w[2];
   bool a_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const long m = m0 + wave * 64 + i * 32 + row;
-    a_ok[i] = m < p.M;
-    const long mm = a_ok[i] ? m : 0;
-    const int img = (int)(mm / HWd);
-    const int rem = (int)(mm - (long)img * HWd);
-    const int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    const int r = wave * 64 + i * 32 + row;
+    a_ok[i] = m0 + r < p.M;
+    int img, oh, ow;
+    walk.at(r, img, oh, ow);
     a_base[i] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + half * 8) * 2;
     if (MODE == 0) {
       a_h[i] = oh * p.stride - p.pad;

@@ -112,15 +112,13 @@ __global__ __launch_bounds__(BM * 2) void conv_kernel(const P pk) {
   const char* a_base[A_LD];
   int a_h[A_LD], a_w[A_LD];
   bool a_ok[A_LD];
-  const long HWd = (long)p.Hd * p.Wd;
+  const DyTileWalk walk(m0, p.Hd, p.Wd);      // (64-bit divisions per row cost more than the 3 K-steps of the stem layer's tile)
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    long m = m0 + 8 * (wave + NW * j) + lrow;
-    a_ok[j] = m < p.M;
-    long mm = a_ok[j] ? m : 0;
-    int img = (int)(mm / HWd);
-    int rem = (int)(mm - (long)img * HWd);
-    int oh = rem / p.Wd, ow = rem - oh * p.Wd;
+    const int r = 8 * (wave + NW * j) + lrow;
+    a_ok[j] = m0 + r < p.M;
+    int img, oh, ow;
+    walk.at(r, img, oh, ow);
     a_base[j] = p.src + ((long)img * p.Hs * p.Ws * p.src_ld + (SMALLC ? 0 : chunk * 8)) * 2;
     if (MODE == 0) {
       a_h[j] = oh * p.stride - p.pad;
