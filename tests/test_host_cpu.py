@@ -191,3 +191,17 @@ def test_checkpoint_reader_refuses_to_run_code(tmp_path):
     torch.save(dict(model=dict(w=torch.zeros(1)), junk=Evil()), f)
     ck = load_checkpoint(str(f))
     assert not (tmp_path / "pwned").exists() and "w" in ck.state_dict
+
+
+def test_tile_walk_reciprocal_is_exact():
+    """dy_common.h DyTileWalk: floor((x + 0.5) * (1 / d)) in float32 equals x // d for every row offset a conv tile can ask for
+    (x < 2^16), every divisor an image can have, and for a reciprocal that is off by one ulp either way (v_rcp_f32)."""
+    x = np.arange(0, 1 << 16, dtype=np.int64)
+    xf = x.astype(np.float32) + np.float32(0.5)
+    for d0 in range(1, 4097, 256):
+        d = np.arange(d0, min(d0 + 256, 4097), dtype=np.int64)
+        inv = (np.float32(1.0) / d.astype(np.float32)).astype(np.float32)
+        want = x[None, :] // d[:, None]
+        for rcp in (inv, np.nextafter(inv, np.float32(0)), np.nextafter(inv, np.float32(2))):
+            got = (xf[None, :] * rcp[:, None]).astype(np.float32).astype(np.int64)
+            assert np.array_equal(got, want), int(d0)
