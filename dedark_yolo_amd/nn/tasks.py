@@ -5,6 +5,7 @@ yaml_model_load (:924-946), guess_model_scale (:950-965) -- same names, argument
 """
 import contextlib
 import math
+import os
 import re
 from copy import deepcopy
 from pathlib import Path
@@ -14,8 +15,13 @@ import torch.nn as nn
 import yaml
 
 from .. import ops
-from .modules import (AsffDetect, AsffDoubLevel, AsffTribeLevel, C2f, Concat, Conv, Detect, MFRU, RFBblock, SPPF, Upsample,
-                      lowlight_recovery)
+from .modules import (AsffDetect, AsffDoubLevel, AsffTribeLevel, C2f, Concat, Conv, Detect, DyModule, MFRU, RFBblock, SPPF, Tape,
+                      Upsample, lowlight_recovery)
+
+# One autograd node for the whole layer graph (training): the plan walks its nodes forwards with one Tape per module and backwards in
+# reverse, adding the gradients of a multi-consumer output itself -- no autograd.Function per yaml node, no ATen `add` for the fan-outs.
+# DY_GRAPH_BACKWARD=0 keeps one autograd.Function per module (modules.py:_ModuleFn).
+_GRAPH_BACKWARD = os.environ.get("DY_GRAPH_BACKWARD", "1") != "0"
 
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg" / "models" / "v8"
 
@@ -143,6 +149,99 @@ class GraphPlan:
                 off += w
             self.concat_width[i] = off
 
+    # ---- training: the whole graph behind ONE autograd.Function (_GraphFn below)
+    def trainable(self):
+        """Every node is a DyModule (or an nn.Sequential of them): the explicit backward walk covers the graph."""
+        ok = self.__dict__.get("_trainable")
+        if ok is None:
+            ok = all(all(isinstance(mod, DyModule) for mod in (m if isinstance(m, nn.Sequential) else [m])) for m, _, _ in self.nodes)
+            self.__dict__["_trainable"] = ok
+        return ok
+
+    def forward_train(self, x, front_args):
+        n = len(self.nodes)
+        outs, bufs = [None] * n, {}
+        st = dict(tapes=[None] * n, mods=[None] * n, metas=[None] * n)
+        for i, (m, src, as_list) in enumerate(self.nodes):
+            mods = list(m) if isinstance(m, nn.Sequential) else [m]
+            cur = [x if sidx < 0 else outs[sidx] for sidx in src]
+            slot = self.place.get(i)
+            view = None
+            if slot is not None:
+                c, off = slot
+                buf = bufs.get(c)
+                if buf is None:
+                    t = cur[0]
+                    Ho, Wo = _out_hw(m, t)
+                    buf = bufs[c] = ops.empty_nhwc(t.shape[0], self.concat_width[c], Ho, Wo, ops.get_compute_dtype(), t.device)
+                view = buf[:, off:off + m.c_out]
+            tapes, metas = [], []
+            for j, mod in enumerate(mods):
+                tape = Tape()
+                if isinstance(mod, lowlight_recovery):
+                    mod._A, mod._I = front_args           # (None, None) in training: the extractor predicts the filter parameters
+                xs = [mod._adapt(t) for t in cur]
+                o = mod._fwd(tape, *xs, out=view) if (view is not None and j == len(mods) - 1) else mod._fwd(tape, *xs)
+                ol = list(o) if isinstance(o, (list, tuple)) else [o]
+                tapes.append(tape)
+                metas.append([(t.shape, t.dtype, t.device) for t in ol])
+                cur = ol
+            st["tapes"][i], st["mods"][i], st["metas"][i] = tapes, mods, metas
+            outs[i] = cur if len(cur) > 1 or isinstance(o, (list, tuple)) else cur[0]
+            if i in bufs:
+                del bufs[i]
+            for sidx in self.dead_after[i]:
+                outs[sidx] = None
+        st["multi"] = isinstance(outs[-1], (list, tuple))
+        return outs[-1], st
+
+    def backward_train(self, st, gouts, x_needs):
+        from ..ops import as_nhwc, copy2d
+        n = len(self.nodes)
+        grads = [None] * n
+        grads[-1] = list(gouts) if st["multi"] else gouts[0]
+        pgrads, gx = {}, None
+        for i in reversed(range(n)):
+            m, src, _ = self.nodes[i]
+            g, grads[i] = grads[i], None
+            tapes, mods, metas = st["tapes"][i], st["mods"][i], st["metas"][i]
+            st["tapes"][i] = None
+            if g is None:
+                continue                                   # nothing downstream of this node reached the loss
+            gl = list(g) if isinstance(g, (list, tuple)) else [g]
+            for j in reversed(range(len(mods))):
+                mod, tape, meta = mods[j], tapes[j], metas[j]
+                gl = [gg if gg is not None else torch.zeros(mm[0], dtype=mm[1], device=mm[2]) for gg, mm in zip(gl, meta)]
+                if not (getattr(mod, "_planar_grad_ok", False) and all(gg.is_contiguous() and gg.dtype == mm[1] for gg, mm in zip(gl, meta))):
+                    gl = [as_nhwc(gg, mm[1]) for gg, mm in zip(gl, meta)]
+                needs = [(sidx >= 0 or x_needs) for sidx in src] if j == 0 else [True]
+                into = grads[src[0]] if (j == 0 and len(src) == 1 and src[0] >= 0 and isinstance(mod, Conv)) else None
+                if into is not None and into.dim() == 4 and into.dtype == meta[0][1]:
+                    # fan-out: a later consumer already left a gradient for this node's input -- the data gradient adds into it
+                    mod._bwd(tape, *gl, needs=needs, dx_out=into, accumulate=True)
+                    gins = [None]
+                else:
+                    gins = mod._bwd(tape, *gl, needs=needs)
+                gl = list(gins) if isinstance(gins, (list, tuple)) else [gins]
+                assert not tape.stack, f"{type(mod).__name__}: unbalanced tape"
+                for p, gp in tape.pgrads.items():
+                    pgrads[id(p)] = gp if id(p) not in pgrads else pgrads[id(p)] + gp
+            cb = m.__dict__.get("_dy_after_backward")
+            if cb is not None:
+                cb()                                       # data-parallel trainer: this layer's gradients are enqueued
+            for sidx, gin in zip(src, gl):
+                if gin is None:
+                    continue
+                if sidx < 0:
+                    gx = gin if gx is None else gx + gin
+                elif grads[sidx] is None:
+                    grads[sidx] = gin
+                elif isinstance(gin, torch.Tensor) and gin.dim() == 4 and gin.dtype == grads[sidx].dtype and gin.shape == grads[sidx].shape:
+                    copy2d(gin, grads[sidx], accumulate=True)      # fan-out: add into the gradient the later consumer left (ours alone)
+                else:
+                    grads[sidx] = grads[sidx] + gin
+        return gx, pgrads
+
     def run(self, x, call_layer):
         outs = [None] * len(self.nodes)
         bufs = {}                                       # concat node -> its buffer of this pass
@@ -164,6 +263,22 @@ class GraphPlan:
             for sidx in self.dead_after[i]:
                 outs[sidx] = None                     # last consumer done: the buffer goes back to the allocator now
         return outs[-1]
+
+
+class _GraphFn(torch.autograd.Function):
+    """forward(plan, front_args, n_params, x, *params) -> the last node's output(s); backward = GraphPlan.backward_train."""
+
+    @staticmethod
+    def forward(ctx, plan, front_args, params, x, *ptensors):
+        out, st = plan.forward_train(x, front_args)
+        ctx.plan, ctx.st, ctx.params = plan, st, params
+        return tuple(out) if st["multi"] else out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        gx, pgrads = ctx.plan.backward_train(ctx.st, gouts, bool(ctx.needs_input_grad[3]))
+        ctx.st = None
+        return (None, None, None, gx, *[pgrads.get(id(p)) for p in ctx.params])
 
 
 def parse_model(d, ch, verbose=False):
@@ -242,12 +357,23 @@ class BaseModel(nn.Module):
         if plan is None or len(plan.nodes) != len(self.model):
             plan = self.__dict__["_plan"] = GraphPlan(list(self.model))
         eval_front = not self.training
+        if _GRAPH_BACKWARD and self.training and torch.is_grad_enabled() and torch.is_tensor(x) and plan.trainable():
+            params = self.__dict__.get("_graph_params")
+            if params is None:
+                params = self.__dict__["_graph_params"] = tuple(p for p in self.model.parameters() if p.requires_grad)
+            if params or x.requires_grad:
+                out = _GraphFn.apply(plan, (None, None), params, x, *params)
+                return list(out) if isinstance(out, tuple) else out
 
         def call_layer(m, inp, out=None):
             if eval_front and isinstance(m, lowlight_recovery):
                 return m(inp, self.current_dedark_A, self.current_IcA)
             return m(inp) if out is None else m(inp, out=out)
         return plan.run(x, call_layer)
+
+    def train(self, mode=True):
+        self.__dict__.pop("_graph_params", None)          # (requires_grad flags are read when the mode is set)
+        return super().train(mode)
 
     def loss(self, batch, preds=None):
         if not hasattr(self, "criterion"):
@@ -305,6 +431,7 @@ class BaseModel(nn.Module):
 
     def _apply(self, fn):
         self = super()._apply(fn)
+        self.__dict__.pop("_graph_params", None)
         m = self.model[-1]
         if isinstance(m, Detect):
             m.stride = fn(m.stride)
