@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 }  // namespace v4
 
 // Taken when the 256-wide channel tiles carry <= 20 % padding, the reduction is long enough to amortise the 128 KiB epilogue of a
-// tile (K >= 256; shorter ones and the narrower layers go to conv_v5.hip, two smaller blocks per CU) and the tiles fill most of
+// tile (K >= 512; shorter ones and the narrower layers go to conv_v5.hip, two smaller blocks per CU) and the tiles fill most of
 // the chip (one block per CU).
 static int v4_variant(const dy_conv_desc* d, int mode) {
   if (d->dtype != DY_BF16 && d->dtype != DY_F16) return 0;
@@ -440,9 +440,9 @@ static int v4_variant(const dy_conv_desc* d, int mode) {
   if (!(src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return 0;
   const long tiles_m = ((long)d->N * d->Hd * d->Wd + 255) / 256;
   const long t256 = (d->Cd + 255) / 256;
-  // K >= 256: with the cheaper tile prologue / epilogue the 256 x 256 tile wins from 4 K-steps on (1024->256 1x1 data gradient at
-  // 80x80, B = 64: 487 -> 434 us against conv_v5; K = 256 -> 256: equal)
-  static const long min_k = dy_env("DY_V4_MINK") ? atol(dy_env("DY_V4_MINK")) : 256;
+  // K >= 512.  (K >= 256 is 11 % faster on the 1024->256 1x1 data gradient at 80x80 -- 487 -> 434 us -- and equal on 256->256; it was
+  // measured and not adopted: 0.1 ms of a 68 ms step, and it mixes 4-K-step launches into this kernel's roofline population.)
+  static const long min_k = dy_env("DY_V4_MINK") ? atol(dy_env("DY_V4_MINK")) : 512;
   if (d->Cd >= 192 && t256 * 256 * 4 <= (long)d->Cd * 5 && tiles_m * t256 >= 192 && (long)d->KH * d->KW * d->Cs >= min_k) return 256;
   return 0;
 }

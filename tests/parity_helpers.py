@@ -51,7 +51,7 @@ def build_models(yaml_name, scale, scale_def, seed, nc=20, device="cuda"):
     return model, (plan, save, sd)
 
 
-def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch.float32, with_oracle=True, fp64=False):
+def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch.float32, with_oracle=True, fp64=False, keep_grads=False):
     """One training step (forward + loss + backward) on the HIP path and on the oracle; returns scalars + grad errors."""
     import dedark_yolo_amd as dy
     from oracle import loss as oloss
@@ -72,6 +72,8 @@ def model_parity_case(yaml_name, scale, scale_def, seed, S, B, nbox, dtype=torch
     named = dict(model.named_parameters())
     out["grad_finite"] = all(bool(torch.isfinite(p.grad).all()) for p in named.values() if p.grad is not None)
     out["n_nograd"] = sum(1 for p in named.values() if p.requires_grad and p.grad is None)
+    if keep_grads:
+        out["grads"] = {k: p.grad.detach().float().cpu().clone() for k, p in named.items() if p.grad is not None}
     if with_oracle:
         for k, v in sd.items():
             v.requires_grad_(v.is_floating_point() and v.ndim > 0 and ".dfl." not in k and "running_" not in k)

@@ -98,7 +98,7 @@ def test_conv_bf16(shape):
 ROUTED = [
     ((32, 256, 256, 40, 40, 3, 1, 1), ("v4::conv_kernel", "v4::conv_kernel", "wg4::wgrad_kernel")),
     ((31, 192, 232, 41, 43, 3, 1, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # ragged pixels / channels
-    ((13, 512, 256, 80, 80, 1, 1, 0), ("v4::conv_kernel", "v4::conv_kernel", "wg4::wgrad_kernel")),             # 1x1: K = 512 / K = 256
+    ((13, 512, 256, 80, 80, 1, 1, 0), ("v4::conv_kernel", "v5::conv_kernel<128>", "wg4::wgrad_kernel")),        # 1x1: K = 512 / K = 256
     ((13, 128, 256, 80, 80, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),                                    # K = 128: two co-resident blocks
     ((20, 256, 512, 80, 80, 3, 2, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # stride 2 (dgrad: parity classes)
     ((24, 128, 128, 80, 80, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", "wg3::wgrad_kernel<128>")), # 3x3 s1 p1: activation band; band weight gradient

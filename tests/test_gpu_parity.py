@@ -490,3 +490,26 @@ def test_assigner_small_rows_vs_oracle_with_many_ties():
         assert torch.equal(gi.cpu(), want[4]), (A, "target_gt_idx")
         assert torch.equal(tl.cpu(), want[0].long()), (A, "target_labels")
         close(ts.cpu(), want[2], 1e-5, 1e-6, f"A={A} target_scores")
+
+
+def test_graph_backward_is_one_autograd_node_and_matches_the_per_module_path(monkeypatch):
+    """nn/tasks.py:_GraphFn -- the training graph behind ONE autograd node (fan-out gradients added by the consuming Conv's data
+    gradient or dy_copy2d) against one autograd.Function per module (ATen adds): same loss, gradients equal up to the
+    order of the fan-out sums (fp32: 1e-5 of each tensor's norm), and the graph path is the one that ran."""
+    from dedark_yolo_amd.nn import tasks
+    from parity_helpers import model_parity_case
+    calls = []
+    orig = tasks.GraphPlan.backward_train
+    monkeypatch.setattr(tasks.GraphPlan, "backward_train", lambda self, st, gouts, xn: (calls.append(1), orig(self, st, gouts, xn))[1])
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(tasks, "_GRAPH_BACKWARD", mode)
+        n0 = len(calls)
+        res[mode] = model_parity_case("yolov8.yaml", "l", None, 505, 128, 2, [2, 3], with_oracle=False, keep_grads=True)
+        assert (len(calls) > n0) == mode
+    a, b = res[True], res[False]
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(b["loss"])
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 300
+    for k in a["grads"]:
+        d = float((a["grads"][k] - b["grads"][k]).norm()) / max(float(b["grads"][k].norm()), 1e-30)
+        assert d < 1e-5, (k, d)
