@@ -140,7 +140,12 @@ class Conv(DyModule):
         return conv_forward(tape, x, c.weight, None, self.bn, self._act, c.stride[0], c.padding[0], c.dilation[0],
                             self.training, out=out, residual=residual)
 
-    def _bwd(self, tape, dy, needs=(True,), dx_out=None, accumulate=False, add_src=None):
+    _takes_into = True       # GraphPlan.backward_train: `into[k]` = gradient another consumer of input k already left; add into it
+
+    def _bwd(self, tape, dy, needs=(True,), dx_out=None, accumulate=False, add_src=None, into=None):
+        if into is not None and into[0] is not None:
+            conv_backward(tape, dy, need_dx=True, dx_out=into[0], accumulate=True)
+            return None
         return conv_backward(tape, dy, need_dx=needs[0], dx_out=dx_out, accumulate=accumulate, add_src=add_src)
 
 
@@ -227,7 +232,12 @@ class Upsample(DyModule):
     def _fwd(self, tape, x, out=None):
         return ops.upsample_fwd(x, self.scale_factor, out=out)
 
-    def _bwd(self, tape, dy, needs=None):
+    _takes_into = True
+
+    def _bwd(self, tape, dy, needs=None, into=None):
+        if into is not None and into[0] is not None:
+            ops.upsample_bwd(dy, self.scale_factor, dx_out=into[0], accumulate=True)
+            return None
         return ops.upsample_bwd(dy, self.scale_factor)
 
 
@@ -370,37 +380,44 @@ class AsffTribeLevel(DyModule):
             tape.push(saved)
         return self.expand._fwd(tape, fused, tr)
 
-    def _bwd(self, tape, dy, needs=(True, True, True)):
+    _takes_into = True
+
+    def _bwd(self, tape, dy, needs=(True, True, True), into=None):
         dfused = conv_backward(tape, dy)
         s = tape.pop()
         r0, r1, r2, logits = s["r0"], s["r1"], s["r2"], s["logits"]
         B, Cc, H, W = r0.shape
         dt, dev = r0.dtype, r0.device
-        dr = [empty_nhwc(B, Cc, H, W, dt, dev) for _ in range(3)]
+        into = list(into) if into is not None else [None, None, None]
+        # the input this level takes as it is (r_k = x_k): the blend's gradient adds straight into what another consumer left
+        same = self.level
+        acc = [1 if (k == same and into[k] is not None) else 0 for k in range(3)]
+        dr = [into[k] if acc[k] else empty_nhwc(B, Cc, H, W, dt, dev) for k in range(3)]
         lw = ld_of(logits)
         dlog = empty_nhwc(B, lw, H, W, dt, dev)
         call("dy_asff_fuse_bwd", ptr(dfused), ld_of(dfused), ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), ptr(r2), ld_of(r2),
              ptr(logits), lw, ptr(dr[0]), ld_of(dr[0]), ptr(dr[1]), ld_of(dr[1]), ptr(dr[2]), ld_of(dr[2]), ptr(dlog), lw,
-             B * H * W, Cc, 0, 0, 0, ops.dt_id(dt), stream())
+             B * H * W, Cc, acc[0], acc[1], acc[2], ops.dt_id(dt), stream())
         dwv = conv_backward(tape, dlog[:, :3])                                # weight_levels -> [B,24,H,W]
         conv_backward(tape, dwv[:, 16:24], dx_out=dr[2], accumulate=True)     # weight_level_2
         conv_backward(tape, dwv[:, 8:16], dx_out=dr[1], accumulate=True)
         conv_backward(tape, dwv[:, 0:8], dx_out=dr[0], accumulate=True)
         (s0, s1, s2) = s["shapes"]
+        A = [dict(dx_out=t, accumulate=True) if t is not None else {} for t in into]      # add into an existing gradient
         if self.level == 0:
             dp2 = conv_backward(tape, dr[2])                                  # stride_level_2
-            dx2 = ops.maxpool_bwd(dp2, s["a2"], tuple(s2), 3, 2, 1)
-            dx1 = ops.maxpool_bwd(dr[1], s["a1"], tuple(s1), 2, 2, 0)
+            dx2 = ops.maxpool_bwd(dp2, s["a2"], tuple(s2), 3, 2, 1, **A[2])
+            dx1 = ops.maxpool_bwd(dr[1], s["a1"], tuple(s1), 2, 2, 0, **A[1])
             dx0 = dr[0]
         elif self.level == 1:
-            dx2 = conv_backward(tape, dr[2])
+            dx2 = conv_backward(tape, dr[2], **A[2])
             dx1 = dr[1]
-            dx0 = ops.upsample_bwd(dr[0], 2)
+            dx0 = ops.upsample_bwd(dr[0], 2, **A[0])
         else:
             dx2 = dr[2]
-            dx1 = conv_backward(tape, ops.upsample_bwd(dr[1], 2))             # compress_level_1
-            dx0 = conv_backward(tape, ops.upsample_bwd(dr[0], 4))             # compress_level_0
-        return dx0, dx1, dx2
+            dx1 = conv_backward(tape, ops.upsample_bwd(dr[1], 2), **A[1])     # compress_level_1
+            dx0 = conv_backward(tape, ops.upsample_bwd(dr[0], 4), **A[0])     # compress_level_0
+        return tuple(None if into[k] is not None else d for k, d in enumerate((dx0, dx1, dx2)))
 
 
 class GroupBatchnorm2d(nn.Module):

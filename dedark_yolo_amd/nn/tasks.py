@@ -215,13 +215,15 @@ class GraphPlan:
                 if not (getattr(mod, "_planar_grad_ok", False) and all(gg.is_contiguous() and gg.dtype == mm[1] for gg, mm in zip(gl, meta))):
                     gl = [as_nhwc(gg, mm[1]) for gg, mm in zip(gl, meta)]
                 needs = [(sidx >= 0 or x_needs) for sidx in src] if j == 0 else [True]
-                into = grads[src[0]] if (j == 0 and len(src) == 1 and src[0] >= 0 and isinstance(mod, Conv)) else None
-                if into is not None and into.dim() == 4 and into.dtype == meta[0][1]:
-                    # fan-out: a later consumer already left a gradient for this node's input -- the data gradient adds into it
-                    mod._bwd(tape, *gl, needs=needs, dx_out=into, accumulate=True)
-                    gins = [None]
-                else:
-                    gins = mod._bwd(tape, *gl, needs=needs)
+                into = None
+                if j == 0 and getattr(mod, "_takes_into", False):
+                    # fan-out: a later consumer already left a gradient for an input of this node -- the module adds into it (the
+                    # data gradient of a Conv, the blend / pooling / resize adjoints of an ASFF level) and returns None for that input
+                    into = [grads[sidx] if (sidx >= 0 and torch.is_tensor(grads[sidx]) and grads[sidx].dim() == 4 and
+                                            grads[sidx].dtype == meta[0][1]) else None for sidx in src]
+                    if all(t is None for t in into):
+                        into = None
+                gins = mod._bwd(tape, *gl, needs=needs, into=into) if into is not None else mod._bwd(tape, *gl, needs=needs)
                 gl = list(gins) if isinstance(gins, (list, tuple)) else [gins]
                 assert not tape.stack, f"{type(mod).__name__}: unbalanced tape"
                 for p, gp in tape.pgrads.items():
