@@ -12,7 +12,8 @@
 //                         Only rows of KEPT boxes are ever evaluated (<= max_det rows x n columns) instead of the n x n
 //                         mask matrix of the classic GPU NMS, because the reference truncates to max_det anyway.
 //
-// IoU arithmetic follows the oracle: class offset added in f32 (ops.py:259), IoU in f64 without contraction.
+// IoU arithmetic is torchvision's CPU kernel's: class offset added in f32 (ops.py:259), areas / intersection / quotient in f32 with
+// one rounding per operation, quotient widened for the comparison with the double threshold.
 #include <hipcub/hipcub.hpp>
 
 #include "dy_common.h"
@@ -59,15 +60,18 @@ __global__ void nms_offsets_kernel(const int* __restrict__ counts, int* __restri
   seg_end[b] = (int)(b * cap + c);
 }
 
-#pragma clang fp contract(off)
-__device__ inline bool nms_overlaps(const float4 bi, const double area_i, const float4 bj, const double thr) {
-  const double xx1 = fmax((double)bi.x, (double)bj.x), yy1 = fmax((double)bi.y, (double)bj.y);
-  const double xx2 = fmin((double)bi.z, (double)bj.z), yy2 = fmin((double)bi.w, (double)bj.w);
-  const double w = fmax(xx2 - xx1, 0.0), h = fmax(yy2 - yy1, 0.0);
-  const double inter = w * h;
-  const double area_j = ((double)bj.z - (double)bj.x) * ((double)bj.w - (double)bj.y);
-  const double iou = inter / (area_i + area_j - inter);
-  return iou > thr;
+// torchvision's CPU kernel (nms_kernel_impl<float>) evaluates areas, intersection and the quotient in the INPUT dtype, every
+// operation rounded on its own (no FMA in its generic x86-64 build), and widens only the quotient for the comparison against the
+// double threshold.  The explicit _rn intrinsics keep hipcc from contracting or re-associating.
+__device__ inline float nms_area(const float4 b) { return __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y)); }
+
+__device__ inline bool nms_overlaps(const float4 bi, const float area_i, const float4 bj, const double thr) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+  const float inter = __fmul_rn(w, h);
+  const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, nms_area(bj)), inter));
+  return (double)ovr > thr;
 }
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_greedy_kernel(const float* __restrict__ pred, const unsigned long long* __restrict__ keys,
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_greedy_kernel(const float* __
       o[5] = (float)j;
       keep_idx[(long)b * max_det + kept] = idx;
     }
-    const double area_i = ((double)bi.z - (double)bi.x) * ((double)bi.w - (double)bi.y);
+    const float area_i = nms_area(bi);
     for (long j = i + 1 + tid; j < n; j += NMS_THREADS)
       if (!dead[j] && nms_overlaps(bi, area_i, boxes[j], iou_thr)) dead[j] = 1;
     ++kept;

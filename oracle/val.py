@@ -1,7 +1,8 @@
 """Oracle: validation post-processing and mAP.  TEST INFRASTRUCTURE.
 
-`nms` restates torchvision.ops.nms from its documented semantics (torchvision is NOT vendored by the reference and
-its version is unpinned: **parity unpinned** for the kept-index order; everything else here is golden-pinned).
+`nms` restates torchvision.ops.nms's published CPU kernel in the input dtype (f32 on the reference's call path); torchvision
+is NOT vendored by the reference, its version is unpinned and it is absent from the image: **parity unpinned** for the greedy
+stage (no build to run against); everything else here is golden-pinned.
 """
 import numpy as np
 import torch
@@ -52,29 +53,41 @@ def box_iou(b1, b2, eps=1e-7):
 
 
 def nms(boxes, scores, thr):
-    """Greedy NMS with torchvision.ops.nms semantics (UNPINNED): visit boxes by descending score (stable order for
-    ties), suppress a later box when IoU > thr with a kept one; area = (x2-x1)*(y2-y1), no eps; returns kept
-    indices in score order (int64)."""
+    """Greedy NMS with the arithmetic of torchvision.ops.nms's CPU kernel (`nms_kernel_impl<scalar_t>`, torchvision/csrc/ops/cpu/
+    nms_kernel.cpp, called from U/utils/ops.py:261 with f32 boxes that already carry the cls * 7680 offset).  torchvision is not
+    vendored by the reference and absent here, so this follows the PUBLISHED kernel, operation by operation, in the INPUT dtype:
+      areas = (x2 - x1) * (y2 - y1)                      (tensor op, scalar_t)
+      order = scores.sort(stable, descending)
+      for each live i in order: keep it; for every later live j:
+          w = max(0, min(ix2, x2[j]) - max(ix1, x1[j])); h likewise; inter = w * h        (scalar_t, no FMA)
+          ovr = inter / (iarea + areas[j] - inter)        (scalar_t, left to right)
+          suppressed[j] = ovr > iou_threshold             (the only widening: scalar_t quotient vs the double threshold)
+    Returns kept indices in score order (int64).  **Unpinned** in the sense of SURVEY 8(c): no torchvision build exists here to run
+    against; the arithmetic above is what the published source states."""
     n = boxes.shape[0]
     if n == 0:
         return torch.zeros(0, dtype=torch.int64)
     order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order].double()
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    dead = torch.zeros(n, dtype=torch.bool)
+    ft = np.float64 if boxes.dtype == torch.float64 else np.float32
+    b = boxes[order].detach().cpu().numpy().astype(ft, copy=False)
+    x1, y1, x2, y2 = (np.ascontiguousarray(b[:, k]) for k in range(4))
+    area = (x2 - x1) * (y2 - y1)
+    thr = np.float64(thr)
+    zero = ft(0)
+    dead = np.zeros(n, dtype=bool)
     keep = []
     for i in range(n):
         if dead[i]:
             continue
         keep.append(i)
         if i + 1 < n:
-            xx1 = torch.maximum(b[i, 0], b[i + 1:, 0])
-            yy1 = torch.maximum(b[i, 1], b[i + 1:, 1])
-            xx2 = torch.minimum(b[i, 2], b[i + 1:, 2])
-            yy2 = torch.minimum(b[i, 3], b[i + 1:, 3])
-            inter = (xx2 - xx1).clamp(min=0) * (yy2 - yy1).clamp(min=0)
-            iou = inter / (area[i] + area[i + 1:] - inter)
-            dead[i + 1:] |= iou > thr
+            w = np.maximum(zero, np.minimum(x2[i], x2[i + 1:]) - np.maximum(x1[i], x1[i + 1:]))
+            h = np.maximum(zero, np.minimum(y2[i], y2[i + 1:]) - np.maximum(y1[i], y1[i + 1:]))
+            inter = w * h
+            with np.errstate(invalid="ignore", divide="ignore"):
+                ovr = inter / ((area[i] + area[i + 1:]) - inter)
+            assert ovr.dtype == ft
+            dead[i + 1:] |= ovr.astype(np.float64) > thr
     return order[torch.tensor(keep, dtype=torch.int64)]
 
 

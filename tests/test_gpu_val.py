@@ -80,6 +80,19 @@ def test_nms_ties_empty_and_caps():
     assert _check_nms(p2, 0.25, 0.7, max_nms=200) > 10
 
 
+def test_nms_f32_arithmetic_on_borderline_pairs():
+    """Pairs whose IoU crosses 0.7 differently in f32 and f64 (g11_nms_borderline.npz): the kernel must follow torchvision's f32
+    rule, i.e. the oracle -- whose own f64 evaluation keeps a different set (tests/test_oracle_golden.py)."""
+    from util import gold
+    g = gold("g11_nms_borderline")
+    for k in (0, 1):
+        pred = g[f"pred{k}"]
+        kept = _check_nms(pred, 0.25, 0.7)
+        assert kept == pred.shape[2] - int(g[f"n32_{k}"])
+    both = torch.cat((g["pred0"], g["pred1"]), 0)
+    _check_nms(both, 0.25, 0.7)
+
+
 def test_nms_full_size_batch():
     """BASELINE shapes: B=32, nc=20, A=8400 -- checked through size-independent properties (sorted scores, no surviving
     pair above the IoU threshold within a class, every survivor above conf)."""

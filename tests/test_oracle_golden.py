@@ -281,6 +281,28 @@ def test_nms_unpinned_semantics():
     assert oval.nms(boxes, scores, 0.99).tolist() == [3, 0, 1, 2]
 
 
+def test_nms_arithmetic_is_f32_like_torchvision():
+    """g11_nms_borderline.npz (tests/golden/make_nms_borderline.py): 24 (keeper, victim) pairs per image whose IoU on the class-offset
+    f32 boxes lies on opposite sides of 0.7 in f32 and in f64 arithmetic, 12 each way.  torchvision's CPU kernel computes in the
+    input dtype (f32, U/utils/ops.py:261), so the oracle must suppress exactly the `n32` victims -- and an f64 evaluation of the
+    same boxes must suppress the OTHER 12 (the fixture separates the two rules)."""
+    g = gold("g11_nms_borderline")
+    for k in (0, 1):
+        pred, n32, n64 = g[f"pred{k}"], int(g[f"n32_{k}"]), int(g[f"n64_{k}"])
+        pairs = pred.shape[2] // 2
+        got = oval.non_max_suppression(pred, 0.25, 0.7)[0]
+        assert got.shape[0] == 2 * pairs - n32
+        orig = oval.nms
+        try:
+            oval.nms = lambda b, s, t: orig(b.double(), s, t)
+            got64 = oval.non_max_suppression(pred, 0.25, 0.7)[0]
+        finally:
+            oval.nms = orig
+        assert got64.shape[0] == 2 * pairs - n64
+        a, b = set(map(tuple, got.tolist())), set(map(tuple, got64.tolist()))
+        assert len(a - b) == n64 and len(b - a) == n32
+
+
 def test_match_predictions_golden():
     """DetectionValidator._process_batch (val.py:151-174) captured from the reference."""
     g = gold("g6_match")

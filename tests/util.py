@@ -52,3 +52,4 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
     bad = err > tol
     assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {float(err.max()):.3e} " \
                           f"(ref max {float(b.abs().max()):.3e})"
+
