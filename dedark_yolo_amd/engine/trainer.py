@@ -400,7 +400,8 @@ class DetectionTrainer:
         epoch to continue with (`U/engine/trainer.py:580-609`: start_epoch = ckpt['epoch'] + 1; half-precision weights are
         converted back with .float() exactly like the reference does)."""
         if isinstance(ckpt, (str, os.PathLike)):
-            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+            from ..utils.checkpoint import load_raw
+            ckpt = load_raw(ckpt)
         f = self.flat
         names = {id(p): k for k, p in self.model.named_parameters()}
         msd, esd = ckpt["model"], ckpt.get("ema") or ckpt["model"]

@@ -8,8 +8,10 @@ take `ckpt.get('ema') or ckpt['model']`, cast to fp32 and read `.yaml`, `.names`
 
 Here a restricted unpickler maps every class outside torch / the standard containers to an inert record that only keeps the
 pickled attribute dict; walking `_modules` / `_parameters` / `_buffers` of those records reproduces `nn.Module.state_dict()`
-(same key order, same names `model.<i>.<sub>...`), which `DetectionModel.load` consumes.  No code object from the file is ever
-called: classes are looked up in an allow-list, everything else becomes a record.
+(same key order, same names `model.<i>.<sub>...`), which `DetectionModel.load` consumes.  The only callables a file can reach are
+the ones on an EXACT (module, name) allow-list (tensor / storage rebuilders, plain containers, numpy array reconstruction); every
+other global -- any other torch.* or numpy.* name included -- becomes an inert record.  State-dict checkpoints written by this
+package are tried with `torch.load(weights_only=True)` first and never reach the unpickler.
 """
 import collections
 import pickle
@@ -46,22 +48,33 @@ def _record_type(module, name):
     return t
 
 
-_ALLOWED_PREFIXES = ("torch.", "collections.", "numpy.")
-_ALLOWED_EXACT = {("builtins", n) for n in ("set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "complex",
-                                           "slice", "range", "bytearray", "object")} | {
-    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
-    ("copyreg", "_reconstructor"), ("_codecs", "encode")}
+# EXACT (module, name) allow-list: a pickle REDUCE may call whatever find_class returns with arguments of the file's choosing, so
+# a prefix rule such as "everything under torch.* / numpy.*" hands the file every callable of those packages (exec / shell helpers
+# included).  Only what torch.save needs to rebuild tensors, containers and numpy scalars is real; every other name -- other
+# torch.* / numpy.* names too -- becomes an inert record.
+_STORAGES = ("Float", "Half", "BFloat16", "Double", "Long", "Int", "Short", "Char", "Byte", "Bool", "ComplexFloat", "ComplexDouble")
+_DTYPES = ("float32", "float", "float16", "half", "bfloat16", "float64", "double", "int64", "long", "int32", "int", "int16", "short",
+           "int8", "uint8", "bool", "complex64", "complex128")
+_ALLOWED_EXACT = (
+    {("builtins", n) for n in ("set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "complex", "slice",
+                               "range", "bytearray", "object")}
+    | {("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("_codecs", "encode")}
+    | {("torch._utils", n) for n in ("_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state")}
+    | {("torch", n + "Storage") for n in _STORAGES} | {("torch", "UntypedStorage"), ("torch.storage", "UntypedStorage"),
+                                                        ("torch.storage", "TypedStorage"), ("torch", "Size"), ("torch", "device"),
+                                                        ("torch", "dtype"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter")}
+    | {("torch", n) for n in _DTYPES}
+    | {(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")}
+    | {("numpy", "ndarray"), ("numpy", "dtype")})
 
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "__builtin__":                       # protocol-2 spelling (torch.save's default protocol)
             module = "builtins"
-        if (module, name) in _ALLOWED_EXACT or module == "torch" or module.startswith(_ALLOWED_PREFIXES):
-            if module.startswith("torch.nn.modules") or module.startswith("torch.nn.parallel"):
-                return _record_type(module, name)          # nn.Conv2d & co. are only needed for their tensors
+        if (module, name) in _ALLOWED_EXACT:
             return super().find_class(module, name)
-        return _record_type(module, name)                  # ultralytics.*, pathlib.*, types.SimpleNamespace, ...
+        return _record_type(module, name)                  # ultralytics.*, torch.nn.modules.*, pathlib.*, any other torch.* / numpy.* ...
 
 
 class _PickleModule:
@@ -111,6 +124,15 @@ def _plain(o, depth=0):
     return o
 
 
+def load_raw(path, device="cpu"):
+    """torch.load that never runs code from the file: weights_only=True first (plain tensors / containers), the restricted
+    unpickler for pickled module objects."""
+    try:                                               # this package's own checkpoints (plain state_dicts) and any tensor-only file
+        return torch.load(path, map_location=device, weights_only=True)
+    except Exception:                                  # pickled module objects (reference last.pt / best.pt): restricted unpickler
+        return torch.load(path, map_location=device, pickle_module=_PickleModule, weights_only=False)
+
+
 def load_checkpoint(path, device="cpu"):
     """Reads a checkpoint written by the reference trainer OR by this package's DetectionTrainer.save_model / YOLO.save.
 
@@ -119,7 +141,7 @@ def load_checkpoint(path, device="cpu"):
       model_sd     fp32 weights of ckpt['model'] (the raw training weights; None if absent)
       yaml, nc, names, train_args, epoch, best_fitness, updates, optimizer, source ('reference-pickle' | 'state-dict')
     """
-    ck = torch.load(path, map_location=device, pickle_module=_PickleModule, weights_only=False)
+    ck = load_raw(path, device)
     if not isinstance(ck, dict):                       # a bare pickled model
         ck = dict(model=ck)
 

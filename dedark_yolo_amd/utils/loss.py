@@ -6,6 +6,7 @@ target grouping, DFL decode, task-aligned assignment, BCE / CIoU / DFL sums and 
 runs in libdedark_yolo.so; there are no host syncs on the way (n_max is taken from the CPU-side batch_idx when available).
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -16,26 +17,31 @@ from ..ops import ld_of, ptr, stream
 REG_MAX = 16
 
 
-_n_max_cache = {}
+_n_max_cache = {}          # id(tensor object) -> (weakref to it, _version, bsz, n_max)
 
 
 def n_max_of(batch_idx, bsz):
     """Largest number of boxes in one image (host value), the reference's `counts.max()` (loss.py:130-132).  batch_idx normally
     lives on the CPU (dataloader), where this is a host-side bincount; DevicePrefetcher / preprocess_batch compute it BEFORE the
-    upload and hand it over as batch['n_max'].  A batch_idx that only exists on the device costs one synchronisation the first
-    time that tensor is seen (cached per storage + version: a resident batch that is reused stays sync-free afterwards)."""
+    upload and hand it over as batch['n_max'].  A batch_idx that only exists on the device costs one synchronisation per tensor
+    OBJECT: the value is remembered for that object alone (weak reference + in-place version counter), so a resident batch that is
+    reused stays sync-free while a fresh upload -- which the caching allocator usually puts at the previous batch's address -- can
+    never inherit another batch's value (too small an n_max would drop ground-truth boxes in dy_loss_prepare_targets)."""
     if batch_idx.numel() == 0:
         return 0
-    bi = batch_idx.detach().view(-1)
-    if not bi.is_cuda:
-        return int(torch.bincount(bi.long(), minlength=bsz).max())
-    key = (bi.data_ptr(), bi.numel(), bi._version, bsz)
-    hit = _n_max_cache.get(key)
-    if hit is None:
+    if not batch_idx.is_cuda:
+        return int(torch.bincount(batch_idx.detach().view(-1).long(), minlength=bsz).max())
+    hit = _n_max_cache.get(id(batch_idx))
+    if hit is not None and hit[0]() is batch_idx and hit[1] == batch_idx._version and hit[2] == bsz:
+        return hit[3]
+    n = int(torch.bincount(batch_idx.detach().view(-1).long(), minlength=bsz).max().item())
+    if len(_n_max_cache) > 64:
+        for k in [k for k, v in _n_max_cache.items() if v[0]() is None]:
+            del _n_max_cache[k]
         if len(_n_max_cache) > 64:
             _n_max_cache.clear()
-        hit = _n_max_cache[key] = int(torch.bincount(bi.long(), minlength=bsz).max().item())
-    return hit
+    _n_max_cache[id(batch_idx)] = (weakref.ref(batch_idx), batch_idx._version, bsz, n)
+    return n
 
 
 _n_max_of = n_max_of

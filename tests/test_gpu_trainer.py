@@ -459,3 +459,19 @@ def test_multi_pack_equals_single_pack(dtype):
     finally:
         import dedark_yolo_amd as dy
         dy.set_compute_dtype(torch.float32)
+
+
+def test_n_max_of_never_inherits_another_batch():
+    """A fresh device-resident batch_idx normally lands at the address the previous one had (caching allocator) with the same
+    element count and version 0: n_max must be recomputed for it (it sizes the ground-truth table of the criterion)."""
+    from dedark_yolo_amd.utils.loss import n_max_of
+    a = torch.tensor([0., 0, 1, 1, 2, 2], device="cuda")
+    assert n_max_of(a, 3) == 2
+    pa = a.data_ptr()
+    del a
+    b = torch.tensor([0., 0, 0, 0, 0, 1], device="cuda")
+    assert b.data_ptr() == pa or True                   # usually the same block; the result must not depend on it
+    assert n_max_of(b, 3) == 5
+    assert n_max_of(b, 3) == 5                          # remembered for this object
+    b[5] = 0                                            # in-place change bumps the version
+    assert n_max_of(b, 3) == 6

@@ -191,6 +191,28 @@ def test_checkpoint_reader_refuses_to_run_code(tmp_path):
     torch.save(dict(model=dict(w=torch.zeros(1)), junk=Evil()), f)
     ck = load_checkpoint(str(f))
     assert not (tmp_path / "pwned").exists() and "w" in ck.state_dict
+    # gadgets INSIDE the packages a checkpoint legitimately names (torch.*, numpy.*): an exact allow-list, not a prefix rule
+    import subprocess
+    import numpy.testing._private.utils as npu
+    import torch.utils.collect_env as tce
+    import torch.hub
+
+    def gadget(fn, *args):
+        class G:
+            def __reduce__(self):
+                return (fn, args)
+        return G()
+    mark = tmp_path / "pwned2"
+    for k, obj in enumerate((gadget(npu.runstring, "open(%r, 'w').write('x')" % str(mark), {}),
+                             gadget(tce.run, "echo x > %s" % mark),
+                             gadget(subprocess.check_call, ["touch", str(mark)]),
+                             gadget(torch.hub.load, "x/y", "z"),
+                             gadget(eval, "open(%r, 'w').write('x')" % str(mark)))):
+        f = tmp_path / f"evil{k}.pt"
+        torch.save(dict(model=dict(w=torch.ones(2)), junk=obj), f)
+        ck = load_checkpoint(str(f))
+        assert not mark.exists(), f"gadget {k} ran"
+        assert torch.equal(ck.state_dict["w"], torch.ones(2))
 
 
 def test_tile_walk_reciprocal_is_exact():
