@@ -368,43 +368,104 @@ class DetectionTrainer:
         self.step_count += 1
         return loss.detach(), items
 
-    # ---------------------------------------------------------------- checkpoints (state_dict based)
+    # ---------------------------------------------------------------- checkpoints (the reference's own format, both ways)
+    def _param_order(self):
+        """The reference optimizer's parameter numbering (build_optimizer, U/engine/trainer.py:626-660): torch numbers the
+        parameters group by group -- group 0 = biases, group 1 = decayed weights, group 2 = BatchNorm weights -- each in
+        model.named_modules() order.  Returns [(flat offset, numel, shape)] in that numbering and the three group sizes."""
+        f = self.flat
+        order = [[], [], []]
+        for p, o, n, g in f.slots:                            # FlatState walks the modules in the same order with the same rule
+            order[{2: 0, 0: 1, 1: 2}[g]].append((o, n, tuple(p.shape)))
+        return order[0] + order[1] + order[2], [len(x) for x in order]
+
+    def optimizer_state_dict(self):
+        """torch.optim-style state_dict of the fused optimizer -- what `optimizer.state_dict()` is in the reference's checkpoint
+        (trainer.py:423) and what its resume hands to `optimizer.load_state_dict` (:591): per-parameter momentum_buffer (SGD) or
+        step / exp_avg / exp_avg_sq (AdamW) + the three param_groups."""
+        f = self.flat
+        flat, sizes = self._param_order()
+        m, m2 = f.m.detach().cpu(), None if f.m2 is None else f.m2.detach().cpu()
+        state = {}
+        for i, (o, n, shape) in enumerate(flat):
+            if self.opt_name == "AdamW":
+                state[i] = dict(step=torch.tensor(float(self.updates)), exp_avg=m[o:o + n].view(shape).clone(),
+                                exp_avg_sq=m2[o:o + n].view(shape).clone())
+            else:
+                state[i] = dict(momentum_buffer=m[o:o + n].view(shape).clone())
+        groups, k = [], 0
+        for gi, cnt in enumerate(sizes):
+            common = dict(lr=float(self.lr0), initial_lr=float(self.lr0), weight_decay=float(self.weight_decay) if gi == 1 else 0.0,
+                          maximize=False, foreach=None, differentiable=False, params=list(range(k, k + cnt)))
+            if self.opt_name == "AdamW":
+                common.update(betas=(float(self.momentum), 0.999), eps=1e-8, amsgrad=False, capturable=False, fused=None)
+            else:
+                common.update(momentum=float(self.momentum), dampening=0, nesterov=True, fused=None)
+            groups.append(common)
+            k += cnt
+        return dict(state=state, param_groups=groups)
+
+    def load_optimizer_state_dict(self, opt):
+        """Inverse of optimizer_state_dict; also reads the optimizer entry of a checkpoint the REFERENCE wrote."""
+        f = self.flat
+        flat, sizes = self._param_order()
+        groups = opt.get("param_groups", [])
+        if [len(g["params"]) for g in groups] != sizes:
+            raise RuntimeError(f"resume: optimizer groups {[len(g['params']) for g in groups]} do not match this model's {sizes}")
+        adam = any("exp_avg" in st for st in opt["state"].values())
+        if adam != (self.opt_name == "AdamW"):
+            raise RuntimeError(f"resume: checkpoint optimizer state does not belong to {self.opt_name}")
+        f.m.zero_()
+        if f.m2 is not None:
+            f.m2.zero_()
+        for i, (o, n, shape) in enumerate(flat):
+            st = opt["state"].get(i)
+            if not st:
+                continue                                      # torch creates state lazily: a parameter that never stepped has none
+            if adam:
+                f.m[o:o + n].copy_(st["exp_avg"].reshape(-1).float())
+                f.m2[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).float())
+            elif st.get("momentum_buffer") is not None:
+                f.m[o:o + n].copy_(st["momentum_buffer"].reshape(-1).float())
+
     def save_model(self, wdir, epoch=0, fitness=None):
-        """last.pt (and best.pt when `fitness` is the best so far) with the keys of the reference checkpoint
-        (`U/engine/trainer.py:408-433`: epoch, best_fitness, model, ema, updates, optimizer, train_args, date, version).  The
-        reference pickles half-precision module objects; here `model` / `ema` are half-precision state_dicts (+ the model yaml),
-        which `YOLO(path)` / `DetectionModel.load` read back, and `optimizer` holds the flat momentum buffers of the fused step."""
-        import datetime
+        """trainer.save_model (U/engine/trainer.py:408-433): last.pt always, best.pt when `fitness` is the best so far -- in the
+        reference's own on-disk format: `model` / `ema` are pickled half-precision DetectionModel OBJECTS under the reference's
+        class paths (utils/checkpoint.py:save_reference_checkpoint; the reference's attempt_load_one_weight loads them, verified by
+        tests/golden/make_ckpt_interop.py), `optimizer` is a torch.optim-style state_dict in the reference's parameter numbering,
+        `train_args` the argument dict.  `dy_state` carries what the reference has no slot for (fp16 loss scale, step counters)."""
+        from ..utils.checkpoint import save_reference_checkpoint
         os.makedirs(wdir, exist_ok=True)
         f = self.flat
         best = getattr(self, "best_fitness", None)
         if fitness is not None and (best is None or fitness >= best):
             self.best_fitness = best = fitness
-        half = lambda sd: {k: (v.half() if v.dtype.is_floating_point else v.clone()).cpu() for k, v in sd.items()}
         ops.flush_bn_counters()
-        ckpt = dict(epoch=int(epoch), best_fitness=best, model=half(self.model.state_dict()), ema=half(f.ema_state_dict(self.model)),
-                    updates=int(self.updates), yaml=getattr(self.model, "yaml", None), nc=getattr(self.model.model[-1], "nc", None),
-                    optimizer=dict(name=self.opt_name, momentum_buffer=f.m.cpu(), exp_avg_sq=None if f.m2 is None else f.m2.cpu(),
-                                   step_count=int(self.step_count), last_opt_step=int(self.last_opt_step), lr0=float(self.lr0),
-                                   momentum=float(self.momentum), weight_decay=float(self.weight_decay)),
-                    train_args={k: v for k, v in vars(self.args).items() if isinstance(v, (int, float, str, bool, type(None), list, tuple))},
-                    date=datetime.datetime.now().isoformat(), version="dedark_yolo_amd-1", state_dict=half(self.model.state_dict()))
+        ema_sd = dict(self.model.state_dict())
+        ema_sd.update(f.ema_state_dict(self.model))           # EMA parameters + float buffers; integer buffers / frozen DFL as they are
+        ta = {k: v for k, v in vars(self.args).items() if isinstance(v, (int, float, str, bool, type(None), list, tuple))}
+        ls = getattr(self, "loss_scale", None)
+        extra = dict(dy_state=dict(opt_name=self.opt_name, step_count=int(self.step_count), last_opt_step=int(self.last_opt_step),
+                                   loss_scale=None if ls is None else [float(v) for v in ls.cpu()], version="dedark_yolo_amd-2"))
         last = os.path.join(wdir, "last.pt")
-        torch.save(ckpt, last)
+        save_reference_checkpoint(last, self.model, ema_state=ema_sd, epoch=int(epoch), best_fitness=best, updates=int(self.updates),
+                                  optimizer=self.optimizer_state_dict(), train_args=ta, extra=extra)
         if fitness is not None and best == fitness:
-            torch.save(ckpt, os.path.join(wdir, "best.pt"))
+            import shutil
+            shutil.copyfile(last, os.path.join(wdir, "best.pt"))
         return last
 
     def resume_training(self, ckpt):
-        """Restores parameters, EMA, optimizer buffers and counters from a `save_model` checkpoint (dict or path) and returns the
-        epoch to continue with (`U/engine/trainer.py:580-609`: start_epoch = ckpt['epoch'] + 1; half-precision weights are
-        converted back with .float() exactly like the reference does)."""
-        if isinstance(ckpt, (str, os.PathLike)):
-            from ..utils.checkpoint import load_raw
-            ckpt = load_raw(ckpt)
+        """Restores parameters, EMA, optimizer state and counters from last.pt -- written by save_model above OR by the reference's
+        trainer (pickled module objects; read without the reference package by utils/checkpoint.py) -- and returns the epoch to
+        continue with (`U/engine/trainer.py:580-609`: start_epoch = ckpt['epoch'] + 1; the half-precision weights are converted
+        back with .float() exactly like the reference does)."""
+        from ..utils.checkpoint import load_checkpoint
+        ck = load_checkpoint(ckpt) if isinstance(ckpt, (str, os.PathLike)) else ckpt
         f = self.flat
+        msd = ck.model_sd if ck.model_sd is not None else ck.state_dict
+        esd = ck.state_dict                                   # `ema` when present, else `model` (reference precedence)
         names = {id(p): k for k, p in self.model.named_parameters()}
-        msd, esd = ckpt["model"], ckpt.get("ema") or ckpt["model"]
         for p, o, n, _ in f.slots:
             k = names[id(p)]
             f.p[o:o + n].copy_(msd[k].float().reshape(-1).to(f.p.device))
@@ -419,19 +480,19 @@ class DetectionTrainer:
         for k, b in self.model.named_buffers():                     # integer buffers (num_batches_tracked)
             if not b.dtype.is_floating_point and k in msd:
                 b.copy_(msd[k].to(b.device))
-        opt = ckpt.get("optimizer")
-        if opt is not None:
-            if opt.get("name") != self.opt_name:
-                raise RuntimeError(f"resume: checkpoint was written by {opt.get('name')}, this trainer runs {self.opt_name}")
-            f.m.copy_(opt["momentum_buffer"].to(f.m.device))
-            if f.m2 is not None and opt.get("exp_avg_sq") is not None:
-                f.m2.copy_(opt["exp_avg_sq"].to(f.m2.device))
-            self.step_count, self.last_opt_step = int(opt.get("step_count", 0)), int(opt.get("last_opt_step", -1))
-            self.best_fitness = ckpt.get("best_fitness")
-        self.updates = int(ckpt.get("updates", 0))
+        if ck.optimizer is not None:
+            self.load_optimizer_state_dict(ck.optimizer)
+        self.best_fitness = ck.best_fitness
+        self.updates = int(ck.updates or 0)
+        dy_state = getattr(ck, "dy_state", None) or {}
+        self.step_count = int(dy_state.get("step_count", 0))
+        self.last_opt_step = int(dy_state.get("last_opt_step", -1))
+        ls = dy_state.get("loss_scale")
+        if ls is not None and getattr(self, "loss_scale", None) is not None:      # GradScaler state: {scale, finite steps so far}
+            self.loss_scale.copy_(torch.tensor(ls, dtype=torch.float32))
         ops.bump_weights_epoch()
         self.pack_plan.repack(self.model)
-        return int(ckpt.get("epoch", -1)) + 1
+        return int(ck.epoch if ck.epoch is not None else -1) + 1
 
     @contextlib.contextmanager
     def ema_weights(self):
@@ -441,16 +502,20 @@ class DetectionTrainer:
         if f.ema is None:
             yield self.model
             return
-        keep_p, keep_b = f.p.clone(), f.buf_flat.clone()
-        f.p.copy_(f.ema)
-        f.buf_flat.copy_(f.buf_ema)
-        ops.bump_weights_epoch()
+        has_buf = f.buf_ema is not None and f.buf_flat.numel() > 0
+        keep_p, keep_b = f.p.clone(), (f.buf_flat.clone() if has_buf else None)
         try:
+            f.p.copy_(f.ema)
+            if has_buf:
+                f.buf_flat.copy_(f.buf_ema)
+            ops.bump_weights_epoch()
             yield self.model
         finally:
             f.p.copy_(keep_p)
-            f.buf_flat.copy_(keep_b)
+            if has_buf:
+                f.buf_flat.copy_(keep_b)
             ops.bump_weights_epoch()
+            self.pack_plan.repack(self.model)                 # one launch; a lazy re-pack would cost one per layer in the next step
 
     def validate(self, val_loader):
         """trainer.validate() (engine/trainer.py:471-480): the validator on the EMA weights, forced to fp32 as the fork does

@@ -375,6 +375,7 @@ class AsffTribeLevel(DyModule):
         fused = empty_nhwc(B, Cc, H, W, r0.dtype, r0.device)
         call("dy_asff_fuse_fwd", ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), ptr(r2), ld_of(r2), ptr(logits), ld_of(logits),
              ptr(fused), ld_of(fused), B * H * W, Cc, ops.dt_id(r0.dtype), stream())
+        ops.emu_round(fused)
         if tape is not None:
             saved.update(r0=r0, r1=r1, r2=r2, logits=logits, shapes=(x0.shape, x1.shape, x2.shape))
             tape.push(saved)
@@ -398,6 +399,7 @@ class AsffTribeLevel(DyModule):
         call("dy_asff_fuse_bwd", ptr(dfused), ld_of(dfused), ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), ptr(r2), ld_of(r2),
              ptr(logits), lw, ptr(dr[0]), ld_of(dr[0]), ptr(dr[1]), ld_of(dr[1]), ptr(dr[2]), ld_of(dr[2]), ptr(dlog), lw,
              B * H * W, Cc, acc[0], acc[1], acc[2], ops.dt_id(dt), stream())
+        ops.emu_round(dr[0], dr[1], dr[2], dlog)
         dwv = conv_backward(tape, dlog[:, :3])                                # weight_levels -> [B,24,H,W]
         conv_backward(tape, dwv[:, 16:24], dx_out=dr[2], accumulate=True)     # weight_level_2
         conv_backward(tape, dwv[:, 8:16], dx_out=dr[1], accumulate=True)
@@ -657,6 +659,7 @@ class AsffDoubLevel(DyModule):
         fused = empty_nhwc(B, Cc, H, W, r0.dtype, r0.device)
         call("dy_asff_fuse_fwd", ptr(r0), ld_of(r0), ptr(r1), ld_of(r1), None, 0, ptr(logits), ld_of(logits),
              ptr(fused), ld_of(fused), B * H * W, Cc, ops.dt_id(r0.dtype), stream())
+        ops.emu_round(fused)
         if tape is not None:
             tape.push(dict(r0=r0, r1=r1, logits=logits))
         return self.expand._fwd(tape, fused, tr)
@@ -969,6 +972,7 @@ class lowlight_recovery(DyModule):
         out8 = torch.empty((B, H, W, 8), dtype=cd, device=dev).permute(0, 3, 1, 2)
         hp = torch.empty((B, 3, H, W), dtype=f32, device=dev) if tape is not None else None
         call("dy_usm_fwd", ptr(s4), ptr(params), None, ptr(out8), ptr(hp), B, H, W, ops.dt_id(cd), st)
+        ops.emu_round(out8)
         if tape is not None:
             tape.push(dict(x=x, feat=feat, params=params, hp=hp, A=A, I=I))
         return out8[:, :3]

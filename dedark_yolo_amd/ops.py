@@ -30,6 +30,27 @@ def get_compute_dtype():
     return _compute_dtype
 
 
+_emulate_storage = None     # TEST HOOK: fp32 path with every stored activation / gradient tensor rounded to this 16-bit dtype
+
+
+def set_storage_emulation(dt):
+    """Test hook (tests/test_gpu_lowprec.py): with the fp32 compute dtype, round what the 16-bit paths STORE -- pre-BatchNorm conv
+    outputs, activations, data gradients -- to `dt` right after the kernel that produced it, while all arithmetic stays on the
+    golden-pinned fp32 kernels.  That is an ideal 16-bit-storage implementation running on the same GPU: the yardstick that
+    separates kernel error from the rounding error any implementation of that storage format has.  None switches it off."""
+    global _emulate_storage
+    if dt not in (None, torch.bfloat16, torch.float16):
+        raise ValueError("storage emulation: bf16 / fp16 / None")
+    _emulate_storage = dt
+
+
+def emu_round(*tensors):
+    if _emulate_storage is not None:
+        for t in tensors:
+            if t is not None and t.dtype == torch.float32:
+                t.copy_(t.to(_emulate_storage))
+
+
 def bump_weights_epoch():
     global _weights_epoch
     _weights_epoch += 1
@@ -390,7 +411,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
         st = stream()
         rp, rld = (residual.data_ptr(), ld_of(residual)) if residual is not None else (None, 0)
         bp = bn._parameters
-        if _C._prof is None:
+        if _C._prof is None and _emulate_storage is None:
             # conv (raw z + statistics) -> finalize -> affine/activation/residual: three launches, ONE foreign call
             call("dy_conv2d_bn_act_fwd", C.byref(d), pixels, ptr(bp["weight"]), ptr(bp["bias"]), ptr(bn.running_mean), ptr(bn.running_var),
                  float(bn.momentum), float(bn.eps), pa, act, rp, rld, y.data_ptr(), ld_of(y), st)
@@ -398,11 +419,13 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
             _C.set_meta(kind="conv_fwd", shape=f"{Cin}->{Cout} k{KH} s{stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                         bytes=float((B * H * W * Cin + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
             call("dy_conv2d_fwd", C.byref(d), st)
+            emu_round(z)                    # (the statistics come from the f32 accumulators in every dtype)
             call("dy_bn_finalize", ptr(stats), pixels, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                  ptr(bn.running_var), float(bn.momentum), float(bn.eps), pa, pa + sa, pa + 2 * sa, pa + 3 * sa, cout_pad, st)
             _C.set_meta(kind="bn_act_fwd", shape=f"{cout_pad}ch {B}x{Ho}x{Wo}", dtype=str(dtype), flops=0.0,
                         bytes=float(pixels * cout_pad * x.element_size() * (3 if residual is not None else 2)))
             call("dy_bn_act_fwd", ptr(z), ld_of(z), pa, pa + sa, act, rp, rld, ptr(y), ld_of(y), pixels, cout_pad, dt_id(dtype), st)
+            emu_round(y)
         if ctx is not None:
             ctx.z, ctx.aff, ctx.y = z, aff, None
     else:
@@ -425,6 +448,7 @@ def conv_forward(tape, x, weight, bias=None, bn=None, act=ACT_NONE, stride=1, pa
             call("dy_copy2d", ptr(residual), ld_of(residual), ptr(tgt), ld_of(tgt), B * Ho * Wo, cout_pad, 1, dt_id(dtype),
                  stream())
             y = tgt
+        emu_round(y)
         if ctx is not None:
             if has_bn:
                 raise RuntimeError("conv: gradients through an eval-mode BatchNorm are not supported")
@@ -589,7 +613,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src
         if not direct:
             dgb = torch.empty((2, cout_pad), dtype=torch.float32, device=dev)
             gw_, gb_ = dgb[0], dgb[1]
-        if _C._prof is None:
+        if _C._prof is None or _emulate_storage is not None:
             call("dy_bn_act_bwd", dy.data_ptr(), ld_of(dy), z.data_ptr(), ld_of(z), pa, ptr(bn._parameters["weight"]), ctx.act,
                  sums.data_ptr(), dz.data_ptr(), ld_of(dz), gw_.data_ptr(), gb_.data_ptr(), pixels, cout_pad, did, st)
         else:
@@ -599,6 +623,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src
             _C.set_meta(kind="bn_act_bwd_apply", shape=f"{cout_pad}ch {pixels}px", dtype=str(dtype), flops=0.0, bytes=float(pixels * cout_pad * x.element_size() * 3))
             call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(z), ld_of(z), pa, pa + sa, pa + 2 * sa, pa + 3 * sa,
                  ptr(bn.weight), ctx.act, 1, ptr(sums), ptr(dz), ld_of(dz), ptr(gw_), ptr(gb_), pixels, cout_pad, did, st)
+        emu_round(dz)
         if not direct:
             _add_pgrad(tape, bn.weight, gw_)
             _add_pgrad(tape, bn.bias, gb_)
@@ -621,6 +646,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src
                 dz = empty_nhwc(B, cout_pad, Ho, Wo, dtype, dev)
                 call("dy_bn_act_bwd_apply", ptr(dy), ld_of(dy), ptr(y), ld_of(y), None, None, None, None, None, ctx.act, 0,
                      ptr(sums), ptr(dz), ld_of(dz), None, ptr(db), pixels, cout_pad, did, st)
+                emu_round(dz)
             if need_bias and gb_ is None:
                 gd = _grad_dst(ctx.bias)
                 if gd is not None:
@@ -693,6 +719,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src
     _C._prof is not None and _C.set_meta(kind="conv_dgrad", shape=f"{Cin}->{Cout} k{KH} s{ctx.stride} in {B}x{H}x{W}", dtype=str(dtype), flops=2.0 * pixels * Cout * KH * KW * Cin,
                 bytes=float((B * H * W * Cin * (2 if accumulate else 1) + pixels * Cout + Cout * KH * KW * Cin) * x.element_size()))
     call("dy_conv2d_dgrad", C.byref(d), st)
+    emu_round(dxb)
     if dx_out is not None:
         return dx_out
     return dxb if cin_pad == Cin else dxb[:, :Cin]
@@ -721,6 +748,7 @@ def maxpool_bwd(dy, arg, in_shape, k, stride, pad, dx_out=None, accumulate=False
     dx = dx_out if dx_out is not None else empty_nhwc(B, Cc, H, W, dy.dtype, dy.device)
     call("dy_maxpool_bwd", ptr(dy), ld_of(dy), ptr(arg), ptr(dx), ld_of(dx), B, H, W, Cc, k, stride, pad, Ho, Wo,
          1 if (accumulate and dx_out is not None) else 0, dt_id(dy.dtype), stream())
+    emu_round(dx)
     return dx
 
 
@@ -737,6 +765,7 @@ def upsample_bwd(dy, scale, dx_out=None, accumulate=False):
     dx = dx_out if dx_out is not None else empty_nhwc(B, Cc, H, W, dy.dtype, dy.device)
     call("dy_upsample_nearest_bwd", ptr(dy), ld_of(dy), ptr(dx), ld_of(dx), B, H, W, Cc, scale,
          1 if (accumulate and dx_out is not None) else 0, dt_id(dy.dtype), stream())
+    emu_round(dx)
     return dx
 
 

@@ -51,8 +51,11 @@ class _Assignment:
     __slots__ = ("pred_boxes", "gt", "counts", "target_gt_idx", "fg_mask", "norm", "target_label", "target_box", "n_max")
 
 
-def assign(maps, strides, nc, batch_idx, cls, bboxes, n_max=None):
-    """prepare targets + decode + task-aligned assignment; returns an _Assignment of device tensors."""
+def assign(maps, strides, nc, batch_idx, cls, bboxes, n_max=None, frozen=None):
+    """prepare targets + decode + task-aligned assignment; returns an _Assignment of device tensors.
+    `frozen` (test hook, v8DetectionLoss.frozen_assignment): an _Assignment of an earlier call on the same batch whose discrete
+    outcome (tal.py:84-132: target_gt_idx, fg_mask, target labels / boxes and the normalised target score) is reused instead of
+    running the assigner; the predicted boxes are still decoded from THESE maps."""
     B = maps[0].shape[0]
     dev = maps[0].device
     A = sum(m.shape[2] * m.shape[3] for m in maps)
@@ -74,6 +77,12 @@ def assign(maps, strides, nc, batch_idx, cls, bboxes, n_max=None):
     dm = ops.det_maps(maps, strides, nc)
     a.pred_boxes = torch.empty((B, A, 4), dtype=f32, device=dev)
     call("dy_loss_decode", C.byref(dm), ptr(a.pred_boxes), st)
+    if frozen is not None:
+        if frozen.fg_mask.shape != (B, A) or frozen.n_max != n_max:
+            raise ValueError("frozen assignment belongs to another batch / anchor grid")
+        a.target_gt_idx, a.fg_mask, a.norm = frozen.target_gt_idx, frozen.fg_mask, frozen.norm
+        a.target_label, a.target_box = frozen.target_label, frozen.target_box
+        return a
     a.target_gt_idx = torch.empty((B, A), dtype=torch.int32, device=dev)
     a.fg_mask = torch.empty((B, A), dtype=torch.uint8, device=dev)
     a.norm = torch.empty((B, A), dtype=f32, device=dev)
@@ -98,7 +107,8 @@ class _DetLossFn(torch.autograd.Function):
         dev = maps[0].device
         st = stream()
         strides = crit.strides_as_floats()[:n_maps]
-        a = assign(maps, strides, crit.nc, batch["batch_idx"], batch["cls"], batch["bboxes"], batch.get("n_max"))
+        a = assign(maps, strides, crit.nc, batch["batch_idx"], batch["cls"], batch["bboxes"], batch.get("n_max"),
+                   frozen=crit.frozen_assignment)
         dm = ops.det_maps(maps, strides, crit.nc)
         acc = torch.zeros(4, dtype=torch.float64, device=dev)
         call("dy_loss_fwd", C.byref(dm), ptr(a.pred_boxes), ptr(a.fg_mask), ptr(a.norm), ptr(a.target_label), ptr(a.target_box),
@@ -112,6 +122,8 @@ class _DetLossFn(torch.autograd.Function):
              float(getattr(crit.hyp, "lrl", 0.0)), B, ptr(out[0:1]), ptr(out[1:4]), st)
         ctx.crit, ctx.maps, ctx.assign, ctx.acc, ctx.strides = crit, maps, a, acc, strides
         crit.last_assignment = a
+        if crit.keep_maps:
+            crit.last_maps = maps
         loss, items = out[0], out[1:4]
         ctx.mark_non_differentiable(items)
         return loss, items
@@ -130,6 +142,7 @@ class _DetLossFn(torch.autograd.Function):
         g = gloss.detach().to(torch.float32).reshape(1).contiguous()
         call("dy_loss_bwd", C.byref(dm), arr_p, arr_l, ptr(a.pred_boxes), ptr(a.fg_mask), ptr(a.norm), ptr(a.target_label),
              ptr(a.target_box), ptr(ctx.acc), ptr(g), float(crit.hyp.box), float(crit.hyp.cls), float(crit.hyp.dfl), stream())
+        ops.emu_round(*dbufs)
         no = 4 * REG_MAX + crit.nc
         return (None, None, None, *[d[:, :no] for d in dbufs])
 
@@ -181,6 +194,8 @@ class v8DetectionLoss:
         self.use_dfl = m.reg_max > 1
         self.assigner = TaskAlignedAssigner(topk=10, num_classes=self.nc, alpha=0.5, beta=6.0)
         self.last_assignment = None
+        self.frozen_assignment = None        # test hooks: reuse an earlier assignment / keep the Detect maps of the last call
+        self.keep_maps, self.last_maps = False, None
 
     def strides_as_floats(self):
         """Detect.stride as host floats, read back once (a per-step float(tensor) is a device synchronisation)."""

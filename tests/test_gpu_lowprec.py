@@ -227,6 +227,56 @@ def test_l_graph_low_precision_vs_fp32_oracle(dtype):
     assert abs(r["loss"] - r["oracle_loss"]) <= 0.05 * abs(r["oracle_loss"])
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _emulated_storage(model, dtype):
+    """fp32 kernels + 16-bit storage: activations / gradients rounded by ops.set_storage_emulation, conv weights (what the 16-bit
+    paths pack into the compute dtype; BatchNorm affine, biases and the regressor's fully connected layers stay fp32) rounded here."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd import ops
+    if dtype is None:
+        yield
+        return
+    prev = ops.get_compute_dtype()
+    keep = {}
+    try:
+        dy.set_compute_dtype(torch.float32)
+        ops.set_storage_emulation(dtype)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if p.ndim == 4:
+                    keep[k] = p.detach().clone()
+                    p.copy_(p.to(dtype))
+        ops.bump_weights_epoch()
+        yield
+    finally:
+        ops.set_storage_emulation(None)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k in keep:
+                    p.copy_(keep[k])
+        ops.bump_weights_epoch()
+        dy.set_compute_dtype(prev)
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a * b).sum() / max(float(a.norm() * b.norm()), 1e-300))
+
+
+def _permute_assignment(a, perm):
+    """_Assignment of batch[perm]: every field is per image (row b of the new batch = row perm[b] of the old one)."""
+    from dedark_yolo_amd.utils.loss import _Assignment
+    p = perm.to(a.fg_mask.device)
+    out = _Assignment()
+    out.n_max = a.n_max
+    for k in ("target_gt_idx", "fg_mask", "norm", "target_label", "target_box"):
+        setattr(out, k, getattr(a, k).index_select(0, p).contiguous())
+    return out
+
+
 def _perm_batch(batch, perm):
     inv = {int(p): i for i, p in enumerate(perm)}
     out = dict(batch)
@@ -253,7 +303,7 @@ def _full_size(yaml_name, scale, dtype, B, nbox, loss_tol, eval_tol, S=640):
     batch["img"] = batch["img"].pow(2.0)
     perm = torch.roll(torch.arange(B), 1)
 
-    def step(b):
+    def step(b, emulate=None):
         gb = dict(b)
         gb["img"] = b["img"].cuda()
         gb["recovery_loss_batch"] = torch.tensor(0.01, device="cuda")
@@ -261,27 +311,64 @@ def _full_size(yaml_name, scale, dtype, B, nbox, loss_tol, eval_tol, S=640):
             p.grad = None
         # momentum 0 semantics: running stats must not drift between the two evaluations
         st = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
-        loss, items = model(gb)
-        loss.backward()
-        torch.cuda.synchronize()
+        with _emulated_storage(model, emulate):
+            loss, items = model(gb)
+            loss.backward()
+            torch.cuda.synchronize()
         model.load_state_dict(st, strict=False)
         grads = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
         return float(loss), items.float().cpu(), grads
 
     l0, i0, g0 = step(batch)
+    a0 = model.criterion.last_assignment
     l1, i1, g1 = step(_perm_batch(batch, perm))
     assert np.isfinite(l0) and torch.isfinite(i0).all() and all(torch.isfinite(v).all() for v in g0.values())
     assert abs(l0 - l1) <= loss_tol * abs(l0), (l0, l1)
-    # gradients: only the fp32 path is held to a bound -- in 16 bit one flipped rounding re-orders near-tied scores in the
-    # task-aligned top-k, and an anchor that changes its target moves the head gradients by tens of per cent (reported)
     head = [k for k in g0 if k.endswith(".2.weight") and (".cv2." in k or ".cv3." in k)]
     early = [k for k in g0 if g0[k].numel() >= 4096][:3]
     worst = max(_rel(g1[k], g0[k]) for k in head)
     worst_early = max(_rel(g1[k], g0[k]) for k in early)
-    print(f"{yaml_name}@{scale} {dtype} B={B}: loss {l0:.4f} / permuted {l1:.4f}; gradient change under permutation: "
+    print(f"{yaml_name}@{scale} {dtype} B={B}: loss {l0:.4f} / permuted {l1:.4f}; gradient change under permutation, free assignment: "
           f"head {worst:.2e}, first backbone convs {worst_early:.2e}")
     if dtype == torch.float32:
         assert head and worst <= 20 * loss_tol and worst_early <= 2e-2, (worst, worst_early)
+    # 16 bit: one flipped rounding re-orders near-tied scores in the task-aligned top-k and re-targets anchors, so the free-running
+    # numbers above are reported only.  With the ASSIGNMENT FROZEN (tal.py:84-132's discrete outcome of the first evaluation, rows
+    # permuted with the batch) what is left is kernel arithmetic, and that is held to a bound in every dtype.
+    frozen = _permute_assignment(a0, perm)
+    model.criterion.frozen_assignment = frozen
+    try:
+        l2, i2, g2 = step(_perm_batch(batch, perm))
+    finally:
+        model.criterion.frozen_assignment = None
+    worst_f = max(_rel(g2[k], g0[k]) for k in head)
+    worst_early_f = max(_rel(g2[k], g0[k]) for k in early)
+    big = [k for k in g0 if g0[k].numel() >= 64 and float(g0[k].norm()) > 0]
+    cos_min = min(_cos(g2[k], g0[k]) for k in big)
+    print(f"   frozen assignment: loss {l2:.4f}; gradient change under permutation: head {worst_f:.2e}, first backbone convs "
+          f"{worst_early_f:.2e}, worst per-tensor cosine {cos_min:.5f}")
+    assert abs(l2 - l0) <= loss_tol * abs(l0), (l0, l2)
+    if dtype == torch.float32:
+        assert worst_f <= 20 * loss_tol and worst_early_f <= 2e-2 and cos_min >= 0.99, (worst_f, worst_early_f, cos_min)
+    else:
+        # yardstick: the same two evaluations on the fp32 kernels with 16-bit STORAGE (ops.set_storage_emulation): how much an ideal
+        # implementation of this storage format moves under a batch permutation (this random-init graph amplifies a rounding by
+        # four to five orders of magnitude on the way back to the first layers: fp32 itself moves by 5e-3 there)
+        model.criterion.frozen_assignment = a0
+        try:
+            _, _, e0 = step(batch, emulate=dtype)
+            model.criterion.frozen_assignment = frozen
+            _, _, e1 = step(_perm_batch(batch, perm), emulate=dtype)
+        finally:
+            model.criterion.frozen_assignment = None
+            dy.set_compute_dtype(dtype)
+        emu_f = max(_rel(e1[k], e0[k]) for k in head)
+        emu_early = max(_rel(e1[k], e0[k]) for k in early)
+        emu_cos = min(_cos(e1[k], e0[k]) for k in big)
+        print(f"   16-bit storage emulation on the fp32 kernels, same two evaluations: head {emu_f:.2e}, first backbone convs {emu_early:.2e}, "
+              f"worst per-tensor cosine {emu_cos:.5f}")
+        assert worst_f <= 1.5 * emu_f + 2e-2 and worst_early_f <= 1.5 * emu_early + 5e-2 and cos_min >= emu_cos - 0.15, \
+            (worst_f, emu_f, worst_early_f, emu_early, cos_min, emu_cos)
     model.eval()
     with torch.no_grad():
         ya, _ = model(batch["img"].cuda())
@@ -375,3 +462,107 @@ def test_c2f_shortcut_on_large_tile_kernels_vs_fp32(c, hw, B):
     e_dp = max(_rel(g1[k], g0[k]) for k in g0)
     print(f"C2f({c}) {hw}x{hw} B={B}: forward {e_y:.2e} dx {e_dx:.2e} dparam {e_dp:.2e}; dgrad kernels {sorted(kerns)}")
     assert e_y <= 2e-2 and e_dx <= 3e-2 and e_dp <= 3e-2, (e_y, e_dx, e_dp)
+
+
+def _bench_workload(S, B, dtype, want_kernels, seed=11):
+    """The bench.py workload itself (repo yolov8.yaml@L, S x S, batch B, `dtype`): one training evaluation in fp32 on the HIP path
+    (pinned to the reference goldens by test_gpu_parity.py), one in `dtype` with the fp32 run's ASSIGNMENT FROZEN (the discrete
+    outcome of tal.py:84-132 and its target scores: what loss.py:173-187 consumes), so that the comparison sees kernel arithmetic
+    only.  Asserts through dy_last_kernel (the symbol each C-ABI entry reports) that the `dtype` run went through the kernels the
+    benchmark's step is made of, then returns maps / gradients of both runs."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd import _C
+    from parity_helpers import HYP
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from util import load_yaml
+    cfg = load_yaml("yolov8.yaml")
+    cfg["scale"] = "l"
+    dy.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = DetectionModel(cfg, nc=20).cuda().train()
+    model.args = HYP
+    g = np.random.default_rng(seed)
+    batch = make_batch(seed, B, S, [int(n) for n in g.integers(1, 9, B)])
+    batch["img"] = batch["img"].pow(2.0).cuda()
+    batch["recovery_loss_batch"] = torch.tensor(0.01, device="cuda")
+    bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def run(dt, frozen, log=False, emulate=None):
+        dy.set_compute_dtype(dt)
+        model.load_state_dict(bn0, strict=False)
+        for p in model.parameters():
+            p.grad = None
+        if not hasattr(model, "criterion"):
+            model.criterion = model.init_criterion()
+        crit = model.criterion
+        crit.frozen_assignment, crit.keep_maps = frozen, True
+        if log:
+            _C._prof = []
+        try:
+            with _emulated_storage(model, emulate):
+                loss, items = model(dict(batch))
+                loss.backward()
+                torch.cuda.synchronize()
+        finally:
+            rec, _C._prof = _C._prof, None
+            crit.frozen_assignment = None
+        maps = [m.detach().float()[:, :64 + 20].clone() for m in crit.last_maps]
+        grads = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
+        crit.last_maps, crit.keep_maps = None, False
+        return float(loss), maps, grads, crit.last_assignment, rec
+
+    l32, m32, g32, a32, _ = run(torch.float32, None)
+    l32f, _, g32f, _, _ = run(torch.float32, a32)                  # the hook itself: freezing its own assignment changes nothing
+    assert abs(l32f - l32) <= 1e-6 * abs(l32) and max(_rel(g32f[k], g32[k]) for k in g32) <= 1e-5
+    lem, mem, gem, _, _ = run(torch.float32, a32, emulate=dtype)   # ideal 16-bit storage on the fp32 kernels
+    l16, m16, g16, _, rec = run(dtype, a32, log=True)
+    kerns = {r[4] for r in rec if r[4]}
+    print(f"kernels of the {dtype} step: {sorted(kerns)}")
+    for w in want_kernels:
+        assert any(w in k for k in kerns), f"{w} did not run at B={B}, {S}x{S} ({sorted(kerns)})"
+    dy.set_compute_dtype(torch.float32)
+    return (l32, m32, g32), (lem, mem, gem), (l16, m16, g16)
+
+
+def _report_and_bound(tag, ref, emu, got):
+    """Product in 16 bit against the fp32 HIP path, with the 16-bit storage emulation as the yardstick (same frozen assignment in
+    all three).  Bounds: Detect maps and the per-tensor gradient errors no worse than 1.5 x the emulation's (+ a floor); every tensor
+    the emulation itself keeps at cosine >= 0.995 with fp32 must stay at >= 0.99 in the product (the well-conditioned part of the
+    graph: on the rest fp32 is not a yardstick for ANY 16-bit implementation, see test_l_graph_low_precision_vs_fp32_oracle)."""
+    (l32, m32, g32), (lem, mem, gem), (l16, m16, g16) = ref, emu, got
+    e_maps, e_maps_emu = max(_rel(a, b) for a, b in zip(m16, m32)), max(_rel(a, b) for a, b in zip(mem, m32))
+    keys = [k for k in g32 if k in g16 and g32[k].numel() >= 64 and float(g32[k].norm()) > 0 and not k.startswith("model.0.")]
+    cos_p = {k: _cos(g16[k], g32[k]) for k in keys}
+    cos_e = {k: _cos(gem[k], g32[k]) for k in keys}
+    rel_p = sorted(_rel(g16[k], g32[k]) for k in keys)
+    rel_e = sorted(_rel(gem[k], g32[k]) for k in keys)
+    med = lambda v: sorted(v)[len(v) // 2]
+    good = [k for k in keys if cos_e[k] >= 0.995]
+    worst_good = min((cos_p[k], k) for k in good) if good else (1.0, "-")
+    print(f"{tag}: loss fp32 {l32:.4f} / emulation {lem:.4f} / product {l16:.4f}; Detect maps rel L2: product {e_maps:.3e}, emulation "
+          f"{e_maps_emu:.3e}; parameter gradients ({len(keys)} tensors) vs fp32: cosine median product {med(cos_p.values()):.4f} / emulation "
+          f"{med(cos_e.values()):.4f}, worst {min(cos_p.values()):.4f} / {min(cos_e.values()):.4f}; rel L2 median {med(rel_p):.3e} / "
+          f"{med(rel_e):.3e}, worst {rel_p[-1]:.3e} / {rel_e[-1]:.3e}; {len(good)} tensors where the emulation keeps cosine >= 0.995: "
+          f"product worst {worst_good[0]:.5f} ({worst_good[1]})")
+    assert np.isfinite(l16) and abs(l16 - l32) <= max(0.05 * abs(l32), 1.5 * abs(lem - l32)), (l16, lem, l32)
+    assert e_maps <= 1.5 * e_maps_emu + 1e-2, (e_maps, e_maps_emu)
+    assert med(rel_p) <= 1.5 * med(rel_e) + 2e-2 and rel_p[-1] <= 1.5 * rel_e[-1] + 5e-2, (med(rel_p), med(rel_e), rel_p[-1], rel_e[-1])
+    assert med(cos_p.values()) >= med(cos_e.values()) - 0.1, (med(cos_p.values()), med(cos_e.values()))
+    assert worst_good[0] >= 0.99, worst_good
+
+
+def test_c3_bench_workload_routed_kernels_bf16_vs_fp32_frozen_assignment():
+    """BASELINE configs[2] exactly as bench.py runs it: L graph, 640x640, batch 64, bf16.  At this batch the 256->256@40x40 layers
+    are 400 tiles (conv_v4's >= 192-tile rule), the weight gradients take wgrad_v4 / wgrad_v3 and the 128- / 64-channel 3x3 layers
+    the band kernels -- none of which the batch-8 property test reaches."""
+    ref, emu, got = _bench_workload(640, 64, torch.bfloat16,
+                               ("v4::conv_kernel", "wg4::wgrad_kernel", "wg3::wgrad_kernel", "v5::band_kernel<128", "v5::band_kernel<64",
+                                "v5::conv_kernel"))
+    _report_and_bound("C3 B=64 bf16 vs fp32 (frozen assignment)", ref, emu, got)
+
+
+def test_c5_bench_workload_routed_kernels_fp16_vs_fp32_frozen_assignment():
+    """BASELINE configs[4] as bench.py --imgsz 1280 --batch 16 --dtype fp16 runs it."""
+    _supported(torch.float16)
+    ref, emu, got = _bench_workload(1280, 16, torch.float16, ("v4::conv_kernel", "wg4::wgrad_kernel", "v5::band_kernel<128", "v5::band_kernel<64"))
+    _report_and_bound("C5 B=16 fp16 vs fp32 (frozen assignment)", ref, emu, got)

@@ -238,7 +238,8 @@ def test_side_streams_do_not_change_the_step():
 
 
 def test_checkpoint_save_and_resume(tmp_path):
-    """save_model writes last.pt / best.pt with the reference's checkpoint keys (state_dict based); resume_training restores
+    """save_model writes last.pt / best.pt in the reference's own format (pickled module objects under its class paths, torch.optim
+    style optimizer state); resume_training restores
     parameters (through the reference's half-precision round trip), EMA, optimizer buffers and counters, and `YOLO(last.pt)`
     reads the same file."""
     import bench
@@ -250,11 +251,17 @@ def test_checkpoint_save_and_resume(tmp_path):
         b.pop("n_max", None)
         tr.train_step(b, [0.01] * 3, 0.9)
     last = tr.save_model(str(tmp_path), epoch=4, fitness=0.25)
-    ck = torch.load(last, map_location="cpu", weights_only=False)
+    from dedark_yolo_amd.utils.checkpoint import load_checkpoint, load_raw
+    raw = load_raw(last)                                    # pickled module objects under the reference's class paths
     for k in ("epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "date", "version"):
-        assert k in ck, k
-    assert ck["epoch"] == 4 and ck["best_fitness"] == 0.25 and (tmp_path / "best.pt").exists()
-    assert all(v.dtype == torch.float16 for v in ck["model"].values() if v.dtype.is_floating_point)
+        assert k in raw, k
+    assert type(raw["model"]).__name__ == "DetectionModel" and type(raw["model"])._dy_module == "ultralytics.nn.tasks"
+    ck = load_checkpoint(last)
+    assert ck.source == "reference-pickle" and ck.epoch == 4 and ck.best_fitness == 0.25 and (tmp_path / "best.pt").exists()
+    assert set(ck.optimizer) == {"state", "param_groups"} and len(ck.optimizer["param_groups"]) == 3
+    assert sum(len(g["params"]) for g in ck.optimizer["param_groups"]) == len(tr.flat.slots)
+    msd = ck.model_sd
+    assert list(msd) == list(tr.model.state_dict())
     tr2 = _tiny_trainer("SGD", batch=64)
     assert tr2.resume_training(last) == 5
     torch.cuda.synchronize()
@@ -271,8 +278,8 @@ def test_checkpoint_save_and_resume(tmp_path):
     y = YOLO(last)                                          # the predictor reads the same file (weights_only load)
     sd = y.model.state_dict()
     k0 = next(k for k in sd if k.endswith("conv.weight"))
-    assert float((sd[k0].cpu() - ck["ema"][k0].float()).abs().max()) == 0.0      # EMA weights first (nn/tasks.py:640,682)
-    assert float((ck["ema"][k0].float() - ck["model"][k0].float()).abs().max()) > 0.0
+    assert float((sd[k0].cpu() - ck.state_dict[k0]).abs().max()) == 0.0           # EMA weights first (nn/tasks.py:640,682)
+    assert float((ck.state_dict[k0] - ck.model_sd[k0]).abs().max()) > 0.0
 
 
 def test_train_loop_uploads_host_batches_through_the_prefetcher():

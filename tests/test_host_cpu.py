@@ -227,3 +227,104 @@ def test_tile_walk_reciprocal_is_exact():
         for rcp in (inv, np.nextafter(inv, np.float32(0)), np.nextafter(inv, np.float32(2))):
             got = (xf[None, :] * rcp[:, None]).astype(np.float32).astype(np.int64)
             assert np.array_equal(got, want), int(d0)
+
+
+def _written_skeleton(o):
+    """same walk as tests/golden/make_ckpt_interop.py::skeleton, on the writer's stand-in object tree"""
+    import torch
+
+    def plain(v):
+        if isinstance(v, (bool, int, float, str, type(None))):
+            return v
+        if isinstance(v, torch.Tensor):
+            return {"__tensor__": [list(v.shape), str(v.dtype).replace("torch.", "")]}
+        if isinstance(v, (list, tuple)):
+            return {"__seq__": type(v).__name__, "items": [plain(x) for x in v]}
+        if isinstance(v, dict):
+            return {"__dict__": type(v).__module__ + "." + type(v).__name__,
+                    "items": {str(k): plain(x) for k, x in v.items() if k != "filters"}}
+        return {"__object__": type(v).__module__ + "." + type(v).__name__}
+    base = set(torch.nn.Module().__dict__.keys())
+    d = o.__dict__
+    return {"cls": type(o).__module__ + "." + type(o).__qualname__, "training": d["training"],
+            "attrs": {k: plain(v) for k, v in d.items() if k not in base},
+            "params": {k: (None if v is None else plain(v.data)) for k, v in d["_parameters"].items()},
+            "buffers": {k: (None if v is None else plain(v)) for k, v in d["_buffers"].items()},
+            "children": {k: (None if c is None else _written_skeleton(c)) for k, c in d["_modules"].items()}}
+
+
+@pytest.mark.parametrize("tag,name,scale", [("repo_l", "yolov8.yaml", "l"), ("ori_n", "yolov8ori.yaml", "n"), ("v3_l", "yolov8-3.yaml", "l"),
+                                            ("rbf_l", "yolov8-RBF-ASFF.yaml", "l")])
+def test_reference_checkpoint_writer_layout_matches_the_reference(tag, name, scale):
+    """What save_reference_checkpoint pickles for a graph must be, module by module, what the reference itself pickles for it
+    (tests/golden/g12_ref_skeleton.json, captured from `deepcopy(model).half()` of the reference by make_ckpt_interop.py): class
+    path, plain attributes and their values, parameter / buffer names, shapes and dtypes, children in order."""
+    import json
+    from util import load_yaml
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from dedark_yolo_amd.utils.checkpoint import reference_module_object
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "g12_ref_skeleton.json")) as f:
+        want = json.load(f)[tag]
+    cfg = load_yaml(name)
+    cfg["scale"] = scale
+    got = _written_skeleton(reference_module_object(DetectionModel(cfg, nc=20), None, True, dict(box=7.5, cls=0.5, dfl=1.5, lrl=2.0)))
+    bad = []
+
+    def walk(a, b, path):
+        if a["cls"] != b["cls"]:
+            bad.append((path, "class", a["cls"], b["cls"]))
+        for k in set(a["attrs"]) | set(b["attrs"]):
+            if k not in ("yaml",) and a["attrs"].get(k, "<absent>") != b["attrs"].get(k, "<absent>"):
+                bad.append((path, k, a["attrs"].get(k, "<absent>"), b["attrs"].get(k, "<absent>")))
+        for f_ in ("params", "buffers"):
+            if a[f_] != b[f_]:
+                bad.append((path, f_, a[f_], b[f_]))
+        if list(a["children"]) != list(b["children"]):
+            bad.append((path, "children", list(a["children"]), list(b["children"])))
+        for k, c in a["children"].items():
+            if c is not None and b["children"].get(k) is not None:
+                walk(c, b["children"][k], path + "." + k)
+    walk(want, got, tag)
+    assert not bad, bad[:10]
+    wy, gy = want["attrs"]["yaml"]["items"], got["attrs"]["yaml"]["items"]
+    for k in ("nc", "scale", "backbone", "head", "ch"):
+        assert wy[k] == gy[k], k
+
+
+def test_reference_checkpoint_writer_round_trip(tmp_path):
+    """The file names the REFERENCE's classes (and none of this package's), torch.load(weights_only=True) refuses it like any pickled
+    module object, and the restricted reader gets both state_dicts, counters and optimizer back."""
+    import torch
+    from util import load_yaml
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from dedark_yolo_amd.utils.checkpoint import load_checkpoint, save_reference_checkpoint
+    cfg = load_yaml("yolov8-lowlight.yaml")
+    cfg["scales"]["t"] = [0.33, 0.0625, 1024]
+    cfg["scale"] = "t"
+    torch.manual_seed(3)
+    m = DetectionModel(cfg, nc=20)
+    sd = m.state_dict()
+    ema = {k: (v + 0.25 if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    opt = dict(state={0: dict(momentum_buffer=torch.ones(3))}, param_groups=[dict(lr=0.01, params=[0])])
+    path = save_reference_checkpoint(str(tmp_path / "last.pt"), m, ema_state=ema, epoch=7, best_fitness=0.5, updates=11, optimizer=opt,
+                                     train_args=dict(imgsz=64, lrl=2.0), extra=dict(dy_state=dict(step_count=5)))
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    for needle in (b"ultralytics.nn.tasks\nDetectionModel", b"ultralytics.nn.modules.conv\nConv", b"ultralytics.nn.modules.llie\nlowlight_recovery",
+                   b"ultralytics.nn.modules.filtersB\nUsmFilter", b"easydict\nEasyDict", b"torch.nn.modules.conv\nConv2d"):
+        assert needle in pkl, needle
+    assert b"dedark_yolo_amd" not in pkl
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)
+    ck = load_checkpoint(path)
+    assert ck.source == "reference-pickle" and (ck.epoch, ck.updates, ck.nc) == (7, 11, 20) and ck.dy_state["step_count"] == 5
+    assert list(ck.state_dict) == list(sd) and list(ck.model_sd) == list(sd)
+    for k, v in sd.items():
+        w = v.half().float() if v.is_floating_point() else v
+        e = ema[k].half().float() if v.is_floating_point() else v
+        assert torch.equal(ck.model_sd[k], w) and torch.equal(ck.state_dict[k], e), k
+    assert torch.equal(ck.optimizer["state"][0]["momentum_buffer"], torch.ones(3))
+    m2 = DetectionModel(ck.yaml, nc=ck.nc)
+    assert m2.load(ck.state_dict) == len(sd)
