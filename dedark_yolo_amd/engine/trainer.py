@@ -106,6 +106,26 @@ class FlatState:
         return sd
 
 
+class EarlyStopping:
+    """Stops training after `patience` epochs without a fitness improvement (reference ultralytics/utils/torch_utils.py:478-516:
+    `>=` keeps the early zero-fitness epochs from counting, `possible_stop` announces the stop one epoch ahead so that the last
+    epoch is validated even with val=False)."""
+
+    def __init__(self, patience=50):
+        self.best_fitness, self.best_epoch = 0.0, 0
+        self.patience = patience or float("inf")
+        self.possible_stop = False
+
+    def __call__(self, epoch, fitness):
+        if fitness is None:
+            return False
+        if fitness >= self.best_fitness:
+            self.best_epoch, self.best_fitness = epoch, fitness
+        delta = epoch - self.best_epoch
+        self.possible_stop = delta >= (self.patience - 1)
+        return delta >= self.patience
+
+
 class GradBuckets:
     """Layer-aligned gradient buckets.  The all-reduce(sum) of a bucket is issued from inside the backward pass as soon as
     every parameterised layer of the bucket has produced its gradients (RCCL waits on the compute stream at issue time and
@@ -156,10 +176,19 @@ class GradBuckets:
         for b in self.buckets:              # a layer that took no part in this backward (should not happen) is reduced here
             if b["left"] > 0:
                 self.works.append(dist.all_reduce(self.flat.g[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True))
+        ev = self.exposed_events
+        if ev is not None:                  # bench.py --gpus N: how long the compute stream sits in these waits = the part of the
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)     # all-reduce backward did not hide
+            e0.record()
         for w in self.works:
-            w.wait()
+            w.wait()                        # (stream-side wait for the collective's stream; the host does not block)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         self.works.clear()
         self._reset()
+
+    exposed_events = None                   # set to a list to collect (start, end) events around the waits of every finish()
 
 
 class DevicePrefetcher:
@@ -533,18 +562,24 @@ class DetectionTrainer:
             fitness = 0.1 * metrics.get("metrics/mAP50(B)", 0.0) + 0.9 * metrics.get("metrics/mAP50-95(B)", 0.0)
         return metrics, float(fitness)
 
-    def train(self, loader, epochs=None, val_loader=None, save_dir=None):
+    def train(self, loader, epochs=None, val_loader=None, save_dir=None, start_epoch=0):
         """The epoch loop of BaseTrainer._do_train (engine/trainer.py:300-400) around train_step: warm-up / accumulation schedule,
         and at the end of every epoch on rank 0 -- validation on the EMA weights when `val_loader` is given and (args.val or last
         epoch), fitness / best tracking, last.pt / best.pt when `save_dir` is given and (args.save or last epoch)
-        (:366-380, 408-433).  Returns the per-epoch loss items; self.metrics / self.fitness / self.best_fitness hold the rest."""
+        (:366-380, 408-433); then the stop flag of EarlyStopping(args.patience) is broadcast from rank 0 (:389-395) -- the
+        collective doubles as the epoch-boundary barrier: the other ranks wait HERE, on the host, for rank 0's validation / save,
+        not inside the first gradient all-reduce of the next epoch where a long validation would run into the RCCL watchdog.
+        `start_epoch`: resume_training's return value.  Returns the per-epoch loss items; self.metrics / self.fitness /
+        self.best_fitness / self.stop hold the rest."""
         epochs = epochs or self.args.epochs
         nb = len(loader)
         nw = max(round(self.args.warmup_epochs * nb), 100) if self.args.warmup_epochs > 0 else -1
         history = []
         self.metrics, self.fitness = {}, None
         nbs, bs = float(getattr(self.args, "nbs", 64)), max(int(getattr(self.args, "batch", 64)), 1)
-        for epoch in range(epochs):
+        self.stopper = getattr(self, "stopper", None) or EarlyStopping(getattr(self.args, "patience", 50))
+        self.stop = False
+        for epoch in range(start_epoch, epochs):
             for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
                 ni = i + nb * epoch
                 lr, mom = self.lr_factors(ni, nw, epoch, epochs)
@@ -557,9 +592,16 @@ class DetectionTrainer:
                     self.last_opt_step = ni
             history.append([float(v) for v in items])
             if self.rank in (-1, 0):
-                final_epoch = epoch + 1 == epochs
+                final_epoch = epoch + 1 == epochs or self.stopper.possible_stop
                 if val_loader is not None and (getattr(self.args, "val", True) or final_epoch):
                     self.metrics, self.fitness = self.validate(val_loader)
-                if save_dir is not None and (getattr(self.args, "save", True) or final_epoch):
+                self.stop = self.stopper(epoch + 1, self.fitness)
+                if save_dir is not None and (getattr(self.args, "save", True) or epoch + 1 == epochs):
                     self.save_model(os.path.join(str(save_dir), "weights"), epoch=epoch, fitness=self.fitness)
+            if self.world_size > 1 and dist.is_initialized():         # K5: broadcast_object_list([stop], 0) (trainer.py:389-393)
+                flag = [self.stop if self.rank == 0 else None]
+                dist.broadcast_object_list(flag, 0)
+                self.stop = bool(flag[0])
+            if self.stop:
+                break                                                 # every rank leaves the loop in the same epoch
         return history

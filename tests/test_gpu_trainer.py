@@ -419,8 +419,9 @@ def test_train_loop_validates_on_ema_weights_and_tracks_best(tmp_path):
         assert dy.get_compute_dtype() == torch.bfloat16 and tr.model.training
         last, best = tmp_path / "weights" / "last.pt", tmp_path / "weights" / "best.pt"
         assert last.exists() and best.exists()
-        ck = torch.load(last, map_location="cpu", weights_only=False)
-        assert ck["epoch"] == 1 and ck["best_fitness"] == tr.best_fitness >= tr.fitness
+        from dedark_yolo_amd.utils.checkpoint import load_checkpoint
+        ck = load_checkpoint(str(last))                      # the reference's format: pickled module objects (restricted reader)
+        assert ck.epoch == 1 and ck.best_fitness == tr.best_fitness >= tr.fitness
         # live parameters are not the EMA ones (they moved by SGD steps; the EMA barely moved) and were restored after validation
         live = tr.flat.p.detach().clone()
         assert float((live - tr.flat.ema).abs().max()) > 0
