@@ -229,18 +229,22 @@ def workload_tag(args):
     return "custom workload", None
 
 
-def pmc_traffic(tag, kernel):
-    """HBM-side bytes per launch of the kernel symbol from the committed rocprofv3 PMC passes of this same command
-    (tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, separate passes); (None, None) when no summary names the kernel."""
+def pmc_traffic(tag, kernel, calls_per_step):
+    """HBM-side bytes of the kernel symbol from the committed rocprofv3 PMC passes of this same command (tools/pmc_traffic.py:
+    2 x FETCH_SIZE + WRITE_SIZE, separate passes), in the unit of `algorithmic_bytes_per_launch`: per C-ABI CALL of the symbol
+    (one call can be several dispatches: a stride-2 data gradient used to be four).  Returns (bytes per call, dispatches per call,
+    file) or (None, None, None) when no summary names the kernel."""
     if tag is None:
-        return None, None
-    for rnd in ("r02", "r01"):
+        return None, None, None
+    for rnd in ("r03", "r02", "r01"):
         f = f"{rnd}_{tag}_pmc_traffic.json"
         path = os.path.join(ROOT, "profiles", f)
         if not os.path.exists(path):
             continue
         with open(path) as fh:
-            ks = json.load(fh).get("kernels", {})
+            js = json.load(fh)
+        ks = js.get("kernels", {})
+        steps = js.get("steps", 5)                 # tools/profile_round.sh: --steps 3 --warmup 2
         base, _, tail = kernel.partition("+")
         match = lambda k, b: k == b or k.startswith(b + "<") or k.startswith(b + "(")
         hit = [v for k, v in ks.items() if match(k, base)]
@@ -255,8 +259,9 @@ def pmc_traffic(tag, kernel):
                     allmain = sum(v["launches"] for k, v in ks.items() if k.startswith(ns) and not match(k, ns + tail))
                     share = n / max(allmain, 1)
                 tot += share * sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in red)
-            return round(tot / max(n, 1)), "profiles/" + f
-    return None, None
+            calls = max(calls_per_step * steps, 1)
+            return round(tot / calls), round(n / calls, 3), "profiles/" + f
+    return None, None, None
 
 
 def main():
@@ -302,10 +307,12 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        trainer.buckets.exposed_events = []       # events around the compute stream's waits for the bucketed all-reduce
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = run(args.steps)
     torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0             # this rank, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -314,6 +321,15 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
+    per_rank = None
+    if world > 1:
+        ev, trainer.buckets.exposed_events = trainer.buckets.exposed_events, None
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+        mine = torch.tensor([1000 * el_own / args.steps, exposed], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = dict(ms_per_step=[round(float(x[0]), 3) for x in allr], allreduce_exposed_ms_per_step=[round(float(x[1]), 3) for x in allr],
+                        gradient_bytes=int(trainer.flat.n) * 4, buckets=len(trainer.buckets.buckets))
     final_loss = float(loss)
     if not np.isfinite(final_loss):
         raise SystemExit(f"non-finite loss {final_loss}")
@@ -334,6 +350,7 @@ def main():
         out["replicas_in_sync"] = bool(all(torch.equal(hs[0], x) for x in hs))
         out["dist_backend"] = backend
         out["rccl_ranks"] = world if backend == "nccl" else 0
+        out["per_rank"] = per_rank                # own step time of every rank + the all-reduce time backward did not hide
 
     agg = None
     if not args.no_roofline:                      # every rank runs the instrumented steps: they contain the gradient all-reduce
@@ -354,11 +371,13 @@ def main():
         else:
             ach = a["bytes"] / a["n"] / avg_s / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
-        traffic, src = pmc_traffic(tag, name)
-        roof.update(kernel=name, c_abi_entries=sorted(a["entries"]), launches_per_step=a["n"] // psteps,
+        traffic, disp, src = pmc_traffic(tag, name, a["n"] // psteps)
+        roof.update(kernel=name, c_abi_entries=sorted(a["entries"]), launches_per_step=a["n"] // psteps, dispatches_per_launch=disp,
+                    traffic_over_algorithmic=None if traffic is None else round(traffic / max(a["bytes"] / a["n"], 1.0), 3),
                     avg_launch_us=round(avg_s * 1e6, 2), share_of_kernel_time=round(a["ms"] / tot, 3), flop_per_byte=round(intensity, 1),
                     algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]), algorithmic_flops_per_launch=round(a["flops"] / a["n"]),
                     traffic=traffic, traffic_source=src,
+                    units="a launch = one C-ABI call of the symbol; achieved, algorithmic bytes / flops and traffic are all per call",
                     streams="kernel durations taken on ONE stream (DY_WGRAD_STREAM=0 DY_BRANCH_STREAMS=0 equivalent); the timed "
                             "region runs the weight gradients and the coarser Detect levels on side streams")
         out["roofline"] = roof

@@ -562,6 +562,9 @@ class DetectionTrainer:
             fitness = 0.1 * metrics.get("metrics/mAP50(B)", 0.0) + 0.9 * metrics.get("metrics/mAP50-95(B)", 0.0)
         return metrics, float(fitness)
 
+    def _batches(self, loader):
+        return DevicePrefetcher(loader, self.device)
+
     def train(self, loader, epochs=None, val_loader=None, save_dir=None, start_epoch=0):
         """The epoch loop of BaseTrainer._do_train (engine/trainer.py:300-400) around train_step: warm-up / accumulation schedule,
         and at the end of every epoch on rank 0 -- validation on the EMA weights when `val_loader` is given and (args.val or last
@@ -580,7 +583,7 @@ class DetectionTrainer:
         self.stopper = getattr(self, "stopper", None) or EarlyStopping(getattr(self.args, "patience", 50))
         self.stop = False
         for epoch in range(start_epoch, epochs):
-            for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
+            for i, batch in enumerate(self._batches(loader)):
                 ni = i + nb * epoch
                 lr, mom = self.lr_factors(ni, nw, epoch, epochs)
                 if ni <= nw:                                   # trainer.py:320-322: accumulate ramps from 1 to nbs / batch

@@ -116,3 +116,60 @@ def test_bench_shards_are_rank_distinct():
     assert float(a["bboxes"].min()) >= 0 and float(a["bboxes"].max()) <= 1
     assert bench.split_model_name("yolov8n-lowlight.yaml") == ("yolov8-lowlight.yaml", "n")
     assert bench.split_model_name("yolov8l.yaml") == ("yolov8.yaml", "l")
+
+
+def _epoch_worker(rank, world, port, q):
+    """The epoch loop of DetectionTrainer.train with the device work stubbed out (no GPU here): what is under test is the
+    reference's epoch-boundary protocol (engine/trainer.py:366-395) -- rank 0 validates / stops, the flag reaches every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from types import SimpleNamespace
+        from dedark_yolo_amd.engine.trainer import DetectionTrainer
+        tr = DetectionTrainer.__new__(DetectionTrainer)
+        tr.args = SimpleNamespace(epochs=10, warmup_epochs=0.0, nbs=64, batch=64, patience=2, val=True, save=True, lrf=0.01, cos_lr=False,
+                                  warmup_bias_lr=0.1, warmup_momentum=0.8)
+        tr.rank, tr.world_size, tr.device = rank, world, "cpu"
+        tr.lr0, tr.momentum, tr.accumulate, tr.last_opt_step = 0.01, 0.9, 1, -1
+        log = dict(steps=0, vals=[], saves=[])
+        fitness = iter([0.30, 0.40, 0.35, 0.39, 0.20, 0.10, 0.10])          # best at epoch 2 -> patience 2 stops after epoch 4
+        tr._batches = lambda loader: iter(loader)
+
+        def train_step(batch, lr=None, mom=None, step_optimizer=True):
+            log["steps"] += 1
+            return torch.tensor(1.0), torch.tensor([1.0, 2.0, 3.0])
+
+        def validate(val_loader):
+            time.sleep(0.3)                                # rank 0 is busy; the others must wait at the broadcast, not run ahead
+            f = next(fitness)
+            log["vals"].append(f)
+            return {"fitness": f}, f
+        tr.train_step, tr.validate = train_step, validate
+        tr.save_model = lambda wdir, epoch=0, fitness=None: log["saves"].append(epoch)
+        t0 = time.time()
+        hist = tr.train([{}] * 3, epochs=10, val_loader=[{}], save_dir="/tmp/unused")
+        q.put((rank, len(hist), log["steps"], log["vals"], log["saves"], bool(tr.stop), time.time() - t0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_epoch_boundary_stop_broadcast_gloo_ws2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(2):
+        r = q.get(timeout=240)
+        out[r[0]] = r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, n0, s0, v0, sv0, stop0, t0), (_, n1, s1, v1, sv1, stop1, t1) = out[0], out[1]
+    assert n0 == n1 == 4 and s0 == s1 == 12           # both ranks ran exactly 4 epochs of 3 steps: the stop reached rank 1
+    assert v0 == [0.30, 0.40, 0.35, 0.39] and v1 == [] and sv0 == [0, 1, 2, 3] and sv1 == []      # validation / checkpoints on rank 0 only
+    assert stop0 and stop1
+    assert t1 >= 0.9 * 4 * 0.3                        # rank 1 waited for rank 0's validation at every epoch boundary

@@ -207,6 +207,10 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert out["replicas_in_sync"] is True
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out          # cpu_baseline is an N=1 field
+    pr = out["per_rank"]                          # own step time of each rank and the all-reduce time its backward did not hide
+    assert len(pr["ms_per_step"]) == 2 and all(0 < t <= out["ms_per_step"] * 1.05 for t in pr["ms_per_step"])
+    assert len(pr["allreduce_exposed_ms_per_step"]) == 2 and all(0 <= t < out["ms_per_step"] for t in pr["allreduce_exposed_ms_per_step"])
+    assert pr["buckets"] >= 1 and pr["gradient_bytes"] > 0
 
 
 def test_bench_spawns_its_own_ranks():

@@ -49,6 +49,7 @@ def short(name):
 
 def main():
     f, w, out = sys.argv[1:4]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5          # steps the profiled command ran (warm-up included)
     fa, wa = load(f, "FETCH_SIZE"), load(w, "WRITE_SIZE")
     kernels = {}
     for k in set(fa) | set(wa):
@@ -65,7 +66,7 @@ def main():
         calls = sum(v["launches"] for k, v in kernels.items() if any(re.search(p, k) for p in main_pats))
         tot = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in sel)
         classes[cname] = dict(calls=calls, traffic_bytes_total=tot, traffic_bytes_per_call=tot / max(calls, 1))
-    json.dump(dict(note="traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per MI355X_MICROARCH.md HBM section", classes=classes,
+    json.dump(dict(note="traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per MI355X_MICROARCH.md HBM section", steps=steps, classes=classes,
                    kernels=dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"])))),
               open(out, "w"), indent=1)
     for c, v in classes.items():
