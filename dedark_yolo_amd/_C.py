@@ -82,6 +82,7 @@ _SIGS = {
     "dy_cru_fuse_fwd": [vp, i64, vp, i64, i32, i64, i32, vp, i32, vp],
     "dy_cru_fuse_bwd": [vp, i64, vp, i64, vp, i64, i32, i64, i32, vp, vp, i32, vp],
     "dy_bbox_ciou": [vp, vp, i64, vp, vp, vp],
+    "dy_bbox_iou": [vp, vp, i64, i32, i32, f32, vp, vp, vp],
     "dy_dfl_loss": [vp, vp, i64, vp, vp, vp],
     "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],
     "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],

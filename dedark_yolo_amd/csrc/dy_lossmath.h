@@ -77,6 +77,81 @@ DY_HD inline float dy_ciou_grad(const float* b1, const float* b2, float* g) {
   return iou - (rho2 / c2 + v * alpha);
 }
 
+// Every mode of the reference's bbox_iou (ultralytics/utils/metrics.py:75-128): kind 0 IoU, 1 GIoU, 2 DIoU, 3 CIoU; xywh != 0: boxes are
+// (cx, cy, w, h) and w, h enter the areas / aspect term as given (no eps), otherwise (x1, y1, x2, y2) with eps added to h only.
+// g (nullable) = d value / d box1 in box1's OWN coordinates; CIoU's alpha is a constant in the backward (no_grad there).
+DY_HD inline float dy_box_iou_any(const float* b1, const float* b2, int xywh, int kind, float eps, float* g) {
+  float x1, y1, x2, y2, X1, Y1, X2, Y2, w1, h1, w2, h2;
+  if (xywh) {
+    w1 = b1[2]; h1 = b1[3]; w2 = b2[2]; h2 = b2[3];
+    const float hw1 = w1 / 2.f, hh1 = h1 / 2.f, hw2 = w2 / 2.f, hh2 = h2 / 2.f;
+    x1 = b1[0] - hw1; x2 = b1[0] + hw1; y1 = b1[1] - hh1; y2 = b1[1] + hh1;
+    X1 = b2[0] - hw2; X2 = b2[0] + hw2; Y1 = b2[1] - hh2; Y2 = b2[1] + hh2;
+  } else {
+    x1 = b1[0]; y1 = b1[1]; x2 = b1[2]; y2 = b1[3];
+    X1 = b2[0]; Y1 = b2[1]; X2 = b2[2]; Y2 = b2[3];
+    w1 = x2 - x1; h1 = y2 - y1 + eps; w2 = X2 - X1; h2 = Y2 - Y1 + eps;
+  }
+  const float iw = dy_fminf(x2, X2) - dy_fmaxf(x1, X1), ih = dy_fminf(y2, Y2) - dy_fmaxf(y1, Y1);
+  const float iwc = dy_fmaxf(iw, 0.f), ihc = dy_fmaxf(ih, 0.f);
+  const float inter = iwc * ihc;
+  const float uni = w1 * h1 + w2 * h2 - inter + eps;
+  const float iou = inter / uni;
+  const float cw = dy_fmaxf(x2, X2) - dy_fminf(x1, X1), ch = dy_fmaxf(y2, Y2) - dy_fminf(y1, Y1);
+  const float c2 = cw * cw + ch * ch + eps, c_area = cw * ch + eps;
+  const float sx = X1 + X2 - x1 - x2, sy = Y1 + Y2 - y1 - y2;
+  const float rho2 = (sx * sx + sy * sy) / 4.f;
+  float v = 0.f, alpha = 0.f, da = 0.f;
+  if (kind == 3) {
+    da = atanf(w2 / h2) - atanf(w1 / h1);
+    v = 0.40528473456935116f * da * da;          // 4/pi^2
+    alpha = v / (v - iou + (1.f + eps));
+  }
+  const float val = kind == 0 ? iou : kind == 1 ? iou - (c_area - uni) / c_area : kind == 2 ? iou - rho2 / c2 : iou - (rho2 / c2 + v * alpha);
+  if (!g) return val;
+  // partial derivatives wrt the corners (x1, y1, x2, y2) with w1, h1 held fixed, and wrt w1, h1 with the corners held fixed
+  const float diw[4] = {iw >= 0.f ? -dy_gmax(x1, X1) : 0.f, 0.f, iw >= 0.f ? dy_gmin(x2, X2) : 0.f, 0.f};
+  const float dih[4] = {0.f, ih >= 0.f ? -dy_gmax(y1, Y1) : 0.f, 0.f, ih >= 0.f ? dy_gmin(y2, Y2) : 0.f};
+  const float dcw[4] = {-dy_gmin(x1, X1), 0.f, dy_gmax(x2, X2), 0.f};
+  const float dch[4] = {0.f, -dy_gmin(y1, Y1), 0.f, dy_gmax(y2, Y2)};
+  const float drho[4] = {-sx / 2.f, -sy / 2.f, -sx / 2.f, -sy / 2.f};
+  float gc[4];
+  for (int k = 0; k < 4; ++k) {
+    const float dinter = diw[k] * ihc + iwc * dih[k];
+    const float diou = (dinter * uni + inter * dinter) / (uni * uni);          // d uni = -d inter at fixed w1, h1
+    float d = diou;
+    if (kind == 1) {
+      const float dca = dcw[k] * ch + cw * dch[k];
+      d += (-dinter * c_area - uni * dca) / (c_area * c_area);
+    } else if (kind >= 2) {
+      const float dc2 = 2.f * cw * dcw[k] + 2.f * ch * dch[k];
+      d -= (drho[k] * c2 - rho2 * dc2) / (c2 * c2);
+    }
+    gc[k] = d;
+  }
+  // wrt w1 / h1: they enter through uni = w1 h1 + ... and, for CIoU, through atan(w1 / h1)
+  const float den = w1 * w1 + h1 * h1;
+  float gw = -inter * h1 / (uni * uni), gh = -inter * w1 / (uni * uni);
+  if (kind == 1) { gw += h1 / c_area; gh += w1 / c_area; }
+  if (kind == 3) {
+    const float k2 = 0.40528473456935116f * 2.f * da * alpha;                 // - alpha dv = + k2 d atan(w1 / h1)
+    gw += k2 * (h1 / den);
+    gh += k2 * (-w1 / den);
+  }
+  if (xywh) {          // corners = centre -/+ half extent
+    g[0] = gc[0] + gc[2];
+    g[1] = gc[1] + gc[3];
+    g[2] = (gc[2] - gc[0]) / 2.f + gw;
+    g[3] = (gc[3] - gc[1]) / 2.f + gh;
+  } else {             // w1 = x2 - x1, h1 = y2 - y1 + eps
+    g[0] = gc[0] - gw;
+    g[1] = gc[1] - gh;
+    g[2] = gc[2] + gw;
+    g[3] = gc[3] + gh;
+  }
+  return val;
+}
+
 // softmax over n logits -> probabilities p, returns expectation sum_i i*p_i
 DY_HD inline float dy_softmax_expect(const float* x, int n, float* p) {
   float mx = x[0];

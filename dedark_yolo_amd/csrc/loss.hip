@@ -833,6 +833,20 @@ __global__ __launch_bounds__(256) void ciou_pairs_kernel(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void iou_pairs_kernel(const float* __restrict__ b1, const float* __restrict__ b2, long n, int xywh, int kind,
+                                                        float eps, float* __restrict__ out, float* __restrict__ grad_b1) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a[4], b[4], g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a[k] = b1[i * 4 + k]; b[k] = b2[i * 4 + k]; }
+  out[i] = dy_box_iou_any(a, b, xywh, kind, eps, grad_b1 ? g : nullptr);
+  if (grad_b1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) grad_b1[i * 4 + k] = g[k];
+  }
+}
+
 // one thread per (box, side): CE at floor(t) / floor(t)+1 of 16 logits; out[box] = mean over the 4 sides (sides add up through
 // a wave shuffle: 4 neighbouring lanes), grad = d sum(out) / d logits
 __global__ __launch_bounds__(256) void dfl_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, long n_sides,
@@ -862,6 +876,16 @@ extern "C" int dy_bbox_ciou(const float* b1, const float* b2, int64_t n, float* 
   DY_CHECK(n >= 0 && (n == 0 || (b1 && b2 && out)), "dy_bbox_ciou: null operand");
   if (n == 0) return 0;
   ciou_pairs_kernel<<<dy_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(b1, b2, n, out, grad_b1);
+  DY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dy_bbox_iou(const float* b1, const float* b2, int64_t n, int xywh, int kind, float eps, float* out, float* grad_b1,
+                           void* stream) {
+  DY_CHECK(n >= 0 && (n == 0 || (b1 && b2 && out)), "dy_bbox_iou: null operand");
+  DY_CHECK(kind >= 0 && kind <= 3, "dy_bbox_iou: kind %d (0 IoU, 1 GIoU, 2 DIoU, 3 CIoU)", kind);
+  if (n == 0) return 0;
+  iou_pairs_kernel<<<dy_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(b1, b2, n, xywh, kind, eps, out, grad_b1);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -26,37 +26,40 @@ def box_iou(box1, box2, eps=1e-7):
     return inter / (area1 + area2 - inter + eps)
 
 
-class _CIoUPairs(torch.autograd.Function):
-    """CIoU of n xyxy box pairs through dy_bbox_ciou; gradient wrt the first boxes (the second ones are targets)."""
+class _IoUPairs(torch.autograd.Function):
+    """IoU / GIoU / DIoU / CIoU of n box pairs through dy_bbox_iou; gradient wrt the first boxes (the second ones are targets)."""
 
     @staticmethod
-    def forward(ctx, b1, b2):
+    def forward(ctx, b1, b2, xywh, kind, eps):
         from .._C import call
         from ..ops import ptr, stream
         n = b1.shape[0]
         out = torch.empty(n, dtype=torch.float32, device=b1.device)
         grad = torch.empty((n, 4), dtype=torch.float32, device=b1.device) if b1.requires_grad else None
-        call("dy_bbox_ciou", ptr(b1), ptr(b2), n, ptr(out), ptr(grad), stream())
+        if kind == 3 and not xywh and eps == 1e-7:
+            call("dy_bbox_ciou", ptr(b1), ptr(b2), n, ptr(out), ptr(grad), stream())        # the entry the training path's kernels share
+        else:
+            call("dy_bbox_iou", ptr(b1), ptr(b2), n, int(bool(xywh)), kind, float(eps), ptr(out), ptr(grad), stream())
         ctx.grad = grad
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.grad * g[:, None], None
+        return ctx.grad * g[:, None], None, None, None, None
 
 
 def bbox_iou(box1, box2, xywh=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7):
-    """Reference signature (ultralytics/utils/metrics.py:75-128) for the one mode the training path calls
-    (loss.py:71, tal.py:158): xywh=False, CIoU=True, matching leading shapes [..., 4] -> [..., 1].  Device tensors only."""
-    if xywh or not CIoU or GIoU or DIoU or eps != 1e-7:
-        raise NotImplementedError("bbox_iou: only (xywh=False, CIoU=True, eps=1e-7), the mode of the training path, is implemented")
+    """Reference signature and flag precedence (ultralytics/utils/metrics.py:75-128): CIoU over DIoU over GIoU over plain IoU,
+    (cx, cy, w, h) or xyxy boxes, broadcastable leading shapes [..., 4] -> [..., 1].  The training path calls
+    (xywh=False, CIoU=True) (loss.py:71, tal.py:158).  Device tensors only; the gradient flows to box1 (box2 is a target)."""
     if box1.device.type != "cuda":
         raise RuntimeError("bbox_iou needs device tensors (there is no CPU path)")
+    kind = 3 if CIoU else 2 if DIoU else 1 if GIoU else 0
     box1, box2 = torch.broadcast_tensors(box1, box2)
     shape = box1.shape[:-1]
     b1 = box1.reshape(-1, 4).float().contiguous()
     b2 = box2.reshape(-1, 4).float().contiguous().detach()
-    return _CIoUPairs.apply(b1, b2).reshape(*shape, 1)
+    return _IoUPairs.apply(b1, b2, bool(xywh), kind, float(eps)).reshape(*shape, 1)
 
 
 def box_filter(y, frac=0.05):

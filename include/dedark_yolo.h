@@ -240,6 +240,10 @@ int dy_cru_fuse_bwd(const void* o, int64_t o_ld, const void* dres, int64_t d_ld,
 /* CIoU of n box pairs, xyxy f32 (reference ultralytics/utils/metrics.py:75-128 bbox_iou(b1, b2, xywh=False, CIoU=True): eps added to
  * h only, alpha constant in the backward); grad_b1 (nullable) [n,4] = d out[i] / d b1[i]. */
 int dy_bbox_ciou(const float* b1, const float* b2, int64_t n, float* out, float* grad_b1, void* stream);
+/* Every mode of the same function (metrics.py:75-128): kind 0 IoU, 1 GIoU, 2 DIoU, 3 CIoU; xywh != 0: (cx, cy, w, h) boxes, w / h used
+ * as given (:95-99), else xyxy with eps added to h only (:100-104).  grad_b1 (nullable) [n,4] = d out[i] / d b1[i] in b1's own
+ * coordinates (b2 is a target; CIoU's alpha constant as under the reference's no_grad). */
+int dy_bbox_iou(const float* b1, const float* b2, int64_t n, int xywh, int kind, float eps, float* out, float* grad_b1, void* stream);
 /* Distribution focal loss (reference ultralytics/utils/loss.py:75-84 BboxLoss._df_loss): pred_dist [n_boxes*4, 16] logits,
  * target [n_boxes, 4] in [0, 15); out [n_boxes] = mean over the 4 sides; grad (nullable) = d sum(out) / d pred_dist. */
 int dy_dfl_loss(const float* pred_dist, const float* target, int64_t n_boxes, float* out, float* grad, void* stream);

@@ -35,6 +35,39 @@ def ciou(b1, b2, eps=1e-7):
     return (iou - (rho2 / c2 + v * a)).unsqueeze(-1)
 
 
+def bbox_iou(b1, b2, xywh=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7):
+    """Every mode of bbox_iou (U/utils/metrics.py:75-128); [...,4] x [...,4] -> [...,1].  xywh: w, h as given (no eps, :95-99);
+    xyxy: eps on h only (:100-104).  Flag precedence CIoU > DIoU > GIoU > IoU (:113-127)."""
+    if xywh:
+        (x, y, w1, h1), (X, Y, w2, h2) = b1.unbind(-1), b2.unbind(-1)
+        x1, x2, y1, y2 = x - w1 / 2, x + w1 / 2, y - h1 / 2, y + h1 / 2
+        X1, X2, Y1, Y2 = X - w2 / 2, X + w2 / 2, Y - h2 / 2, Y + h2 / 2
+    else:
+        x1, y1, x2, y2 = b1.unbind(-1)
+        X1, Y1, X2, Y2 = b2.unbind(-1)
+        w1, h1 = x2 - x1, y2 - y1 + eps
+        w2, h2 = X2 - X1, Y2 - Y1 + eps
+    inter = (torch.minimum(x2, X2) - torch.maximum(x1, X1)).clamp(min=0) * \
+            (torch.minimum(y2, Y2) - torch.maximum(y1, Y1)).clamp(min=0)
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    if not (CIoU or DIoU or GIoU):
+        return iou.unsqueeze(-1)
+    cw = torch.maximum(x2, X2) - torch.minimum(x1, X1)
+    chh = torch.maximum(y2, Y2) - torch.minimum(y1, Y1)
+    if CIoU or DIoU:
+        c2 = cw ** 2 + chh ** 2 + eps
+        rho2 = ((X1 + X2 - x1 - x2) ** 2 + (Y1 + Y2 - y1 - y2) ** 2) / 4
+        if CIoU:
+            v = (4 / math.pi ** 2) * (torch.atan(w2 / h2) - torch.atan(w1 / h1)) ** 2
+            with torch.no_grad():
+                a = v / (v - iou + (1 + eps))
+            return (iou - (rho2 / c2 + v * a)).unsqueeze(-1)
+        return (iou - rho2 / c2).unsqueeze(-1)
+    c_area = cw * chh + eps
+    return (iou - (c_area - union) / c_area).unsqueeze(-1)
+
+
 def pad_targets(batch_idx, cls, bboxes, bsz, img_wh):
     """v8DetectionLoss.preprocess (loss.py:124-139): group rows per image (order kept), zero-pad to the max
     count, scale normalised xywh by (w,h,w,h) and convert to xyxy.  Returns [B, n_max, 5] (cls, x1,y1,x2,y2)."""

@@ -344,6 +344,32 @@ def g_small():
     save("g5_ap", tp=tp, conf=conf, pred_cls=pcls, target_cls=tcls, p=p, r=r, f1=f1, ap=ap, unique=uc, tpc=tpc, fpc=fpc)
 
 
+def g_iou_modes():
+    """bbox_iou in every mode the public helper has (metrics.py:75-128): xywh / xyxy x IoU / GIoU / DIoU / CIoU, values and the
+    gradient wrt box1, on overlapping, disjoint, nested and identical pairs (g5_iou_modes.npz)."""
+    g = np.random.default_rng(52)
+    n = 96
+    c1, s1 = g.uniform(10, 90, (n, 2)), g.uniform(1, 60, (n, 2))
+    c2, s2 = c1 + g.uniform(-25, 25, (n, 2)), g.uniform(1, 60, (n, 2))
+    c2[:8] = c1[:8] + 200.0                                  # disjoint
+    c2[8:16], s2[8:16] = c1[8:16], s1[8:16] * 0.4            # nested, same centre
+    c2[16:20], s2[16:20] = c1[16:20], s1[16:20]              # identical
+    out = {}
+    for xywh in (True, False):
+        if xywh:
+            a, b = np.concatenate((c1, s1), 1), np.concatenate((c2, s2), 1)
+        else:
+            a, b = np.concatenate((c1 - s1 / 2, c1 + s1 / 2), 1), np.concatenate((c2 - s2 / 2, c2 + s2 / 2), 1)
+        tag = "xywh" if xywh else "xyxy"
+        out[f"{tag}_b1"], out[f"{tag}_b2"] = a.astype(np.float32), b.astype(np.float32)
+        for kind, kw in (("iou", {}), ("giou", dict(GIoU=True)), ("diou", dict(DIoU=True)), ("ciou", dict(CIoU=True))):
+            b1 = T(a.astype(np.float32)).requires_grad_(True)
+            v = bbox_iou(b1, T(b.astype(np.float32)), xywh=xywh, **kw)
+            v.sum().backward()
+            out[f"{tag}_{kind}"], out[f"{tag}_{kind}_grad"] = v.detach(), b1.grad
+    save("g5_iou_modes", **out)
+
+
 # ------------------------------------------------------------------ G6: val-side pure-torch pieces (no torchvision)
 def g_val():
     g = np.random.default_rng(61)
@@ -497,7 +523,7 @@ def g_initbuf():
 if __name__ == "__main__":
     which = sys.argv[1:] or None
     todo = dict(frontend=g_frontend, blocks=g_blocks, models=g_models, assigner=g_assigner, small=g_small, val=g_val, ckpt=g_ckpt,
-                pre=g_pre, variants=g_variants, initbuf=g_initbuf)
+                pre=g_pre, variants=g_variants, initbuf=g_initbuf, iou_modes=g_iou_modes)
     for k, fn in todo.items():
         if not ONLY or k in ONLY:
             fn()

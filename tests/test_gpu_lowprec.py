@@ -433,8 +433,18 @@ def test_ciou_and_dfl_entries_on_reference_vectors():
     close(dl.detach().cpu(), g["dfl"], 1e-5, 1e-6, "dfl")
     dl.sum().backward()
     close(pd.grad.cpu(), g["dfl_grad"], 1e-5, 1e-6, "d dfl / d logits")
-    with pytest.raises(NotImplementedError):
-        bbox_iou(b1, g["b2"].cuda(), xywh=True, CIoU=True)
+    # every other mode of the public helper (metrics.py:75-128) on the reference's vectors: value and gradient wrt box1
+    m = gold("g5_iou_modes")
+    for tag, xywh in (("xywh", True), ("xyxy", False)):
+        for kind, kw in (("iou", {}), ("giou", dict(GIoU=True)), ("diou", dict(DIoU=True)), ("ciou", dict(CIoU=True))):
+            b1 = m[f"{tag}_b1"].clone().cuda().requires_grad_(True)
+            v = bbox_iou(b1, m[f"{tag}_b2"].cuda(), xywh=xywh, **kw)
+            close(v.detach().cpu(), m[f"{tag}_{kind}"], 1e-5, 1e-6, f"{tag} {kind}")
+            v.sum().backward()
+            close(b1.grad.cpu(), m[f"{tag}_{kind}_grad"], 2e-4, 1e-6, f"{tag} {kind} grad")
+    # broadcasting like the reference's (1, 4) against (n, 4)
+    one = bbox_iou(m["xyxy_b1"][:1].cuda(), m["xyxy_b2"].cuda(), xywh=False, GIoU=True)
+    assert one.shape == (m["xyxy_b2"].shape[0], 1)
 
 
 @pytest.mark.parametrize("c,hw,B", [(128, 80, 16), (256, 40, 32), (64, 160, 8)])

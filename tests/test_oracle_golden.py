@@ -273,6 +273,19 @@ def test_val_box_helpers_golden():
     close(oval.scale_boxes((640, 640), g["xyxy"].clone(), (480, 360)), g["scaled"], 0, 1e-6, "scale_boxes")
 
 
+def test_bbox_iou_every_mode_golden():
+    """bbox_iou(xywh / xyxy, IoU / GIoU / DIoU / CIoU) values and d/d box1 captured from the reference (g5_iou_modes.npz)."""
+    from oracle import loss as oloss
+    g = gold("g5_iou_modes")
+    for tag, xywh in (("xywh", True), ("xyxy", False)):
+        for kind, kw in (("iou", {}), ("giou", dict(GIoU=True)), ("diou", dict(DIoU=True)), ("ciou", dict(CIoU=True))):
+            b1 = g[f"{tag}_b1"].clone().requires_grad_(True)
+            v = oloss.bbox_iou(b1, g[f"{tag}_b2"], xywh=xywh, **kw)
+            v.sum().backward()
+            close(v.detach(), g[f"{tag}_{kind}"], 1e-6, 1e-7, f"{tag} {kind}")
+            close(b1.grad, g[f"{tag}_{kind}_grad"], 1e-5, 1e-7, f"{tag} {kind} grad")
+
+
 def test_nms_unpinned_semantics():
     """torchvision is absent: check the restated greedy NMS on a hand case (kept order = score order)."""
     boxes = torch.tensor([[0., 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.5]])
