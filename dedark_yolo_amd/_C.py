@@ -35,6 +35,13 @@ class DetMaps(C.Structure):
                 ("nc", i32), ("n_levels", i32), ("dtype", i32)]
 
 
+class AugSample(C.Structure):
+    """dy_aug_sample (include/dedark_yolo.h)"""
+    _fields_ = [("src", vp * 4), ("sh", i32 * 4), ("sw", i32 * 4), ("pitch", i64 * 4), ("rect", (i32 * 6) * 4), ("n_src", i32),
+                ("canvas_h", i32), ("canvas_w", i32), ("hsv", i32), ("flipud", i32), ("fliplr", i32), ("minv", C.c_double * 6),
+                ("lut", (C.c_uint8 * 256) * 3)]
+
+
 _SIGS = {
     "dy_version": [],
     "dy_frontend_init": [],
@@ -83,6 +90,10 @@ _SIGS = {
     "dy_cru_fuse_bwd": [vp, i64, vp, i64, vp, i64, i32, i64, i32, vp, vp, i32, vp],
     "dy_bbox_ciou": [vp, vp, i64, vp, vp, vp],
     "dy_bbox_iou": [vp, vp, i64, i32, i32, f32, vp, vp, vp],
+    "dy_aug_resize_u8": [vp, i32, i32, i64, vp, i32, i32, i64, vp],
+    "dy_aug_letterbox": [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32, vp, vp],
+    "dy_aug_mosaic_warp": [vp, i32, i32, i32, vp, vp],
+    "dy_dark_channel_prior": [vp, i32, i32, i32, vp, vp, vp],
     "dy_dfl_loss": [vp, vp, i64, vp, vp, vp],
     "dy_loss_fwd": [C.POINTER(DetMaps), vp, vp, vp, vp, vp, vp, vp],
     "dy_loss_finish": [vp, vp, f32, f32, f32, f32, i32, vp, vp, vp],

@@ -323,6 +323,12 @@ class DetectionTrainer:
         batch["img"] = out
         batch["clean_img"] = clean
         batch["recovery_loss_batch"] = (self.mse_acc / n).float().reshape(())
+        if both and getattr(a, "dark_channel_prior", False):
+            # detect/train.py:81-97: dedark_A / IcA of the darkened batch.  The reference computes them per image on the host (a
+            # device->host copy + a Python loop) and nothing downstream reads them in train mode, so the device version
+            # is opt-in (args.dark_channel_prior); it is deterministic where the reference's is not (data/augment.py).
+            from ..data.augment import dark_channel_prior
+            batch["dedark_A"], batch["IcA"] = dark_channel_prior(out)
         return batch
 
     # ---------------------------------------------------------------- step

@@ -335,6 +335,32 @@ int dy_conv2d_wgrad_forked(void* wait_for, const void* x, int64_t x_ld, int N, i
 int dy_stream_fork(void* from, void* to);
 int dy_frontend_init(void); /* uploads the gaussian taps (call once per process, outside graph capture) */
 
+/* ---- device-side input pipeline ----------------------------------------------------------------------------------
+ * The pixel work of the reference's dataloader workers (ultralytics/data/augment.py:118-603,745-751, data/base.py:142-169) and of the
+ * trainer's dark-channel loop (models/yolo/detect/train.py:42-68).  Images are uint8 HWC BGR (cv2.imread layout) in device memory. */
+typedef struct dy_aug_sample {
+  const uint8_t* src[4];   /* the (up to) four images of a mosaic, at their load_image size; one image for the letterbox case */
+  int32_t sh[4], sw[4];
+  int64_t pitch[4];        /* bytes per row */
+  int32_t rect[4][6];      /* x1a, y1a, x2a, y2a on the canvas, x1b, y1b in the image (Mosaic._mosaic4, augment.py:166-188) */
+  int32_t n_src, canvas_h, canvas_w;
+  int32_t hsv, flipud, fliplr;
+  double minv[6];          /* inverse of RandomPerspective's 2x3 matrix as cv::warpAffine inverts it (output -> canvas) */
+  uint8_t lut[3][256];     /* RandomHSV's hue / saturation / value tables (augment.py:493-497) */
+} dy_aug_sample;
+/* cv2.resize(INTER_LINEAR) of load_image (base.py:152-157). */
+int dy_aug_resize_u8(const uint8_t* src, int sh, int sw, int64_t src_pitch, uint8_t* dst, int dh, int dw, int64_t dst_pitch, void* stream);
+/* LetterBox + Format (augment.py:559-591,745-751): resize to new_h x new_w, border 114 (top / left given), out = uint8 [3, out_h, out_w] RGB. */
+int dy_aug_letterbox(const uint8_t* src, int sh, int sw, int64_t src_pitch, int new_h, int new_w, int top, int left, int out_h, int out_w,
+                     uint8_t* out, void* stream);
+/* Mosaic canvas -> cv2.warpAffine(borderValue 114) -> RandomHSV -> RandomFlip x2 -> Format for B samples in one launch (augment.py:158-195,
+ * 323-345,486-499,527-532,745-751); samples: DEVICE array of B descriptors; out = uint8 [B, 3, out_h, out_w] RGB = batch['img']. */
+int dy_aug_mosaic_warp(const dy_aug_sample* samples, int B, int out_h, int out_w, uint8_t* out, void* stream);
+/* DarkChannel / AtmLight / DarkIcA of preprocess_batch (train.py:42-68,81-96) without the device->host copy and the Python loop:
+ * img f32 [B,3,H,W] in [0,1] (the darkened batch) -> A [B,3] (0..255 scale, as train.py:95), ica [B,1,H,W].  Deterministic: ties of the
+ * reference's unstable argsort go by pixel index, the rows DarkIcA leaves uninitialised use the per-channel formula. */
+int dy_dark_channel_prior(const float* img, int B, int H, int W, float* A, float* ica, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
