@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov8l.yaml")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--pipeline", default="resident", choices=["resident", "device", "host"],
+                    help="resident: pre-staged batches in HBM (the contract's timed region, default); device: decoded dataset in HBM, "
+                         "mosaic / affine / HSV / flip rendered on the device every step; host: decoded dataset in pinned host memory, "
+                         "source images uploaded every step (PCIe-inclusive), rendered on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -295,11 +299,40 @@ def main():
     trainer = DetectionTrainer(cfg)
     trainer.setup(DetectionModel(args.model, nc=nc))
     batches = [synth_batch(1234 + 17 * rank + i, args.batch, args.imgsz, nc, device) for i in range(4)]
+    loader = None
+    if args.pipeline != "resident":
+        # the step BEFORE the hot path: a synthetic decoded dataset (uint8 HWC at its load_image size, 1..8 boxes per
+        # image) goes through the device input pipeline every step instead of pre-staged batches
+        from dedark_yolo_amd.data import DeviceAugmentLoader
+        g = np.random.default_rng(4321 + rank)
+        n_img = max(4 * args.batch, 256)
+        ims, labs = [], []
+        for i in range(n_img):
+            h, w = (args.imgsz, int(g.integers(args.imgsz * 5 // 8, args.imgsz + 1))) if i % 2 else (int(g.integers(args.imgsz * 5 // 8, args.imgsz + 1)), args.imgsz)
+            ims.append(g.integers(0, 256, (h, w, 3), dtype=np.uint8))
+            k = int(g.integers(1, 9))
+            labs.append(dict(cls=g.integers(0, nc, (k, 1)).astype(np.float32),
+                             bboxes=np.concatenate((g.uniform(0.2, 0.8, (k, 2)), g.uniform(0.05, 0.35, (k, 2))), 1).astype(np.float32)))
+        loader = DeviceAugmentLoader(ims, labs, args.imgsz, args.batch, device=device, resident=args.pipeline == "device", seed=99 + rank)
+        gammas = [b["gamma"] for b in batches]
+        state = dict(it=iter(loader), k=0)
+
+    def next_loader_batch():
+        try:
+            b = next(state["it"])
+        except StopIteration:
+            state["it"] = iter(loader)
+            b = next(state["it"])
+        state["k"] += 1
+        return b, gammas[state["k"] % len(gammas)]
 
     def run(n):
         for i in range(n):
-            b = dict(batches[i % len(batches)])
-            trainer.args.dark_param = b["gamma"]
+            if loader is None:
+                b = dict(batches[i % len(batches)])
+                trainer.args.dark_param = b["gamma"]
+            else:
+                b, trainer.args.dark_param = next_loader_batch()
             loss, items = trainer.train_step(b)
         return loss
 
@@ -340,9 +373,16 @@ def main():
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"{wl}: {args.model}, {args.imgsz}x{args.imgsz}, "
                                     f"{args.dtype}, batch {args.batch}/GPU, nc={nc}, gamma~U(5,10), full train step "
-                                    "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, inputs resident in HBM",
+                                    "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, " +
+                                    {"resident": "inputs resident in HBM",
+                                     "device": "decoded dataset resident in HBM, mosaic/affine/HSV/flip rendered on the device every step",
+                                     "host": "decoded dataset in pinned host memory: source images uploaded every step (PCIe-inclusive), "
+                                             "rendered on the device"}[args.pipeline],
                            global_batch=args.batch * world, parallelism=f"dp{world}"),
                final_loss=round(final_loss, 4))
+    if loader is not None:
+        out["pipeline"] = dict(mode=args.pipeline, dataset_images=len(loader.shapes),
+                               uploaded_mb_per_step=round(loader.uploaded_bytes / max(state["k"], 1) / 1e6, 1))
     if world > 1:                                 # replicas must stay bit-identical: same start state, same summed gradients
         h = trainer.flat.p.double().sum().reshape(1)
         hs = [torch.zeros_like(h) for _ in range(world)]

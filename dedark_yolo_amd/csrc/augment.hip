@@ -14,6 +14,10 @@
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
+// HIP's __fmul_rn / __fsub_rn / __dmul_rn are plain operators on AMD targets: they document the intent; what keeps hipcc from contracting
+// `1 - s * h` or `m1 * y + m2` into a fused multiply-add (one rounding instead of two: off by one level at exact .5 ties) is
+// -ffp-contract=off for this file (csrc/Makefile)
+
 namespace {
 
 __device__ inline int rint_i(double v) { return (int)rint(v); }          // saturate_cast<int>(double) = cvRound (ties to even)

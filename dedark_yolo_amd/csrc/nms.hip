@@ -60,6 +60,7 @@ __global__ void nms_offsets_kernel(const int* __restrict__ counts, int* __restri
   seg_end[b] = (int)(b * cap + c);
 }
 
+// (HIP's __f*_rn intrinsics are plain operators on AMD targets: csrc/Makefile builds this file with -ffp-contract=off)
 // torchvision's CPU kernel (nms_kernel_impl<float>) evaluates areas, intersection and the quotient in the INPUT dtype, every
 // operation rounded on its own (no FMA in its generic x86-64 build), and widens only the quotient for the comparison against the
 // double threshold.  The explicit _rn intrinsics keep hipcc from contracting or re-associating.

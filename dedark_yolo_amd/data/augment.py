@@ -394,6 +394,5 @@ def dark_channel_prior(img):
     B, _, H, W = img.shape
     A = torch.empty((B, 3), dtype=torch.float32, device=img.device)
     ica = torch.empty((B, 1, H, W), dtype=torch.float32, device=img.device)
-    ws = torch.empty(B * (H * W + 1024), dtype=torch.int32, device=img.device)
-    call("dy_dark_channel_prior", ptr(img), B, H, W, ptr(A), ptr(ica), ptr(ws), stream())
+    call("dy_dark_channel_prior", ptr(img), B, H, W, ptr(A), ptr(ica), stream())
     return A, ica

@@ -159,3 +159,20 @@ def test_full_size_batch_properties_and_train_step():
         assert np.isfinite(float(loss))
     finally:
         dy.set_compute_dtype(torch.float32)
+
+
+def test_loader_resident_and_host_modes_agree():
+    """DeviceAugmentLoader: the decoded dataset in HBM (resident) or in pinned host memory with the next batch's source images uploaded on
+    a copy stream -- same seeds, same batches, bit for bit; the host mode really moves bytes; the caller's global RNG state is untouched."""
+    from dedark_yolo_amd.data import DeviceAugmentLoader
+    ims, labels = synth_dataset(5, 12, 96)
+    random.seed(123)
+    before = random.getstate()
+    a = list(DeviceAugmentLoader(ims, labels, 96, 4, resident=True, seed=7))
+    lh = DeviceAugmentLoader(ims, labels, 96, 4, resident=False, seed=7)
+    b = list(lh)
+    torch.cuda.synchronize()
+    assert len(a) == len(b) == 3 and lh.uploaded_bytes > 0 and random.getstate() == before
+    for x, y in zip(a, b):
+        assert torch.equal(x["img"], y["img"]) and torch.equal(x["bboxes"], y["bboxes"]) and torch.equal(x["batch_idx"], y["batch_idx"])
+        assert x["img"].shape == (4, 3, 96, 96) and x["n_max"] == y["n_max"]
