@@ -293,32 +293,17 @@ class DeviceAugmenter:
     def plan(self, index, rnd=_random, nprnd=np.random):
         return plan_train_sample(index, self.shapes, self.buffer, self.imgsz, self.hyp, rnd, nprnd)
 
-    def render(self, plans):
-        """pixels of a list of plans: uint8 [B, 3, s, s] RGB on the device (one launch)"""
-        from .._C import AugSample, call
+    def render(self, plans, staging=None):
+        """pixels of a list of plans: uint8 [B, 3, s, s] RGB on the device (one launch on the current stream).  `staging`: optional
+        pinned uint8 host tensor (>= B * sizeof(dy_aug_sample)) the descriptors are written into and copied from asynchronously;
+        without it the copy comes from pageable memory and blocks the host."""
+        from .._C import call
         from ..ops import ptr, stream
-        import ctypes as C
         B, s = len(plans), self.imgsz
-        arr = (AugSample * B)()
-        for k, p in enumerate(plans):
-            a = arr[k]
-            a.n_src = len(p.sources)
-            for j, (src, r) in enumerate(zip(p.sources, p.rects)):
-                im = self.images[src]
-                a.src[j], a.sh[j], a.sw[j], a.pitch[j] = im.data_ptr(), im.shape[0], im.shape[1], im.stride(0)
-                for q in range(6):
-                    a.rect[j][q] = int(r[q])
-            a.canvas_h, a.canvas_w = p.canvas_hw
-            minv = invert_affine(p.M[:2])
-            for q in range(6):
-                a.minv[q] = float(minv.reshape(-1)[q])
-            a.hsv = int(p.hsv_gains is not None)
-            if a.hsv:
-                for c_ in range(3):
-                    C.memmove(a.lut[c_], p.luts[c_].ctypes.data, 256)
-            a.flipud, a.fliplr = int(p.flipud), int(p.fliplr)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        dev = host.to(self.device)
+        nbytes = B * descriptor_bytes()
+        host = staging[:nbytes] if staging is not None else torch.empty(nbytes, dtype=torch.uint8)
+        fill_descriptors(plans, self.images, host.data_ptr())
+        dev = host.to(self.device, non_blocking=staging is not None)
         out = torch.empty((B, 3, s, s), dtype=torch.uint8, device=self.device)
         call("dy_aug_mosaic_warp", ptr(dev), B, s, s, ptr(out), stream())
         self._keep = dev                                      # descriptor array stays alive until the next call
@@ -332,6 +317,36 @@ class DeviceAugmenter:
         n_max = max([len(c) for c, _ in lab] + [0])
         return dict(img=img, batch_idx=bi, cls=cls, bboxes=bb, n_max=n_max, im_file=[f"{i}" for i in indices],
                     ori_shape=[self.shapes[i] for i in indices], resized_shape=[(self.imgsz, self.imgsz)] * len(indices))
+
+
+def descriptor_bytes():
+    import ctypes as C
+    from .._C import AugSample
+    return C.sizeof(AugSample)
+
+
+def fill_descriptors(plans, images, address):
+    """dy_aug_sample[len(plans)] at `address` (host memory owned by the caller) for plans over `images` (device tensors by dataset index)"""
+    import ctypes as C
+    from .._C import AugSample
+    arr = (AugSample * len(plans)).from_address(address)
+    for k, p in enumerate(plans):
+        a = arr[k]
+        a.n_src = len(p.sources)
+        for j, (src, r) in enumerate(zip(p.sources, p.rects)):
+            im = images[src]
+            a.src[j], a.sh[j], a.sw[j], a.pitch[j] = im.data_ptr(), im.shape[0], im.shape[1], im.stride(0)
+            rj = a.rect[j]
+            rj[0], rj[1], rj[2], rj[3], rj[4], rj[5] = int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5])
+        a.canvas_h, a.canvas_w = p.canvas_hw
+        minv = invert_affine(p.M[:2]).reshape(-1)
+        m = a.minv
+        m[0], m[1], m[2], m[3], m[4], m[5] = (float(v) for v in minv)
+        a.hsv = int(p.hsv_gains is not None)
+        if a.hsv:
+            for c_ in range(3):
+                C.memmove(a.lut[c_], p.luts[c_].ctypes.data, 256)
+        a.flipud, a.fliplr = int(p.flipud), int(p.fliplr)
 
 
 def invert_affine(M):

@@ -16,21 +16,31 @@ from ..utils.metrics import DetMetrics, box_iou
 
 
 def match_predictions(detections, labels, iouv):
-    """DetectionValidator._process_batch (val.py:151-174). detections [N,6] (xyxy, conf, cls), labels [M,5] (cls, xyxy),
-    host tensors -> bool [N, len(iouv)]: per threshold, candidate pairs (IoU >= thr, same class) sorted by IoU descending,
-    then one label per detection and one detection per label (np.unique keeps the first = best occurrence)."""
-    iou = box_iou(labels[:, 1:], detections[:, :4])
-    correct = np.zeros((detections.shape[0], len(iouv)), dtype=bool)
-    same_cls = labels[:, 0:1] == detections[:, 5]
-    for k in range(len(iouv)):
-        li, di = torch.where((iou >= iouv[k]) & same_cls)
-        if li.shape[0]:
-            m = torch.cat((torch.stack((li, di), 1), iou[li, di][:, None]), 1).numpy()
-            if li.shape[0] > 1:
-                m = m[m[:, 2].argsort()[::-1]]
-                m = m[np.unique(m[:, 1], return_index=True)[1]]
-                m = m[np.unique(m[:, 0], return_index=True)[1]]
-            correct[m[:, 1].astype(int), k] = True
+    """Which detections count as true positives at each IoU threshold: detections [N,6] (xyxy, conf, cls), labels [M,5] (cls, xyxy),
+    host tensors -> bool [N, len(iouv)].  The rule of the reference's `_process_batch` (ultralytics/models/yolo/detect/val.py:151-174),
+    stated directly instead of through its sort / unique calls: per threshold, among the (label, detection) pairs of equal class with
+    IoU >= threshold,
+      1. every detection keeps ONE label, the one it overlaps most (an exact IoU tie goes to the higher label index: the order the
+         reference's reversed ascending sort leaves equal keys in);
+      2. every label keeps ONE of the detections that chose it -- the one with the LOWEST detection index (its second `np.unique` runs on
+         rows that the first one has re-ordered by detection index, so it is not the best-overlapping one).
+    The detections that survive both steps are correct at that threshold."""
+    iou = box_iou(labels[:, 1:], detections[:, :4]).numpy()
+    n_lab, n_det = iou.shape
+    correct = np.zeros((n_det, len(iouv)), dtype=bool)
+    if n_lab == 0 or n_det == 0:
+        return torch.from_numpy(correct)
+    same_cls = (labels[:, 0:1] == detections[:, 5]).numpy()
+    thr = np.asarray(iouv, dtype=iou.dtype)
+    for k in range(len(thr)):
+        cand = (iou >= thr[k]) & same_cls
+        dets = np.flatnonzero(cand.any(0))
+        if dets.size == 0:
+            continue
+        score = np.where(cand[:, dets], iou[:, dets], -1.0)
+        chosen = n_lab - 1 - np.argmax(score[::-1], axis=0)          # step 1 (argmax of the flipped column: last maximum)
+        keep = np.unique(chosen, return_index=True)[1]               # step 2: first = lowest detection index per label
+        correct[dets[keep], k] = True
     return torch.from_numpy(correct)
 
 

@@ -328,3 +328,23 @@ def test_reference_checkpoint_writer_round_trip(tmp_path):
     assert torch.equal(ck.optimizer["state"][0]["momentum_buffer"], torch.ones(3))
     m2 = DetectionModel(ck.yaml, nc=ck.nc)
     assert m2.load(ck.state_dict) == len(sd)
+
+
+def test_match_predictions_equals_the_references_sort_unique_formulation():
+    """engine/validator.match_predictions states the matching rule directly; oracle/val.match_predictions keeps the reference's own
+    argsort / np.unique sequence (pinned by g6_match).  Dense random scenes: many labels per detection and detections per label."""
+    from dedark_yolo_amd.engine.validator import match_predictions
+    from oracle import val as oval
+    iouv = torch.linspace(0.5, 0.95, 10)
+    g = np.random.default_rng(8)
+    for trial in range(30):
+        nl, nd = int(g.integers(0, 12)), int(g.integers(0, 60))
+        c = g.uniform(50, 300, (nl, 2))
+        s = g.uniform(20, 120, (nl, 2))
+        lab = torch.tensor(np.concatenate((g.integers(0, 3, (nl, 1)), c - s / 2, c + s / 2), 1), dtype=torch.float32).reshape(nl, 5)
+        pick = g.integers(0, max(nl, 1), nd)
+        dc = (c[pick] if nl else np.zeros((nd, 2))) + g.normal(0, 6, (nd, 2))
+        ds = (s[pick] if nl else np.ones((nd, 2))) * np.exp(g.normal(0, 0.1, (nd, 2)))
+        det = torch.tensor(np.concatenate((dc - ds / 2, dc + ds / 2, g.random((nd, 1)), g.integers(0, 3, (nd, 1))), 1), dtype=torch.float32).reshape(nd, 6)
+        a, b = match_predictions(det, lab, iouv), oval.match_predictions(det, lab, iouv)
+        assert torch.equal(a, b), trial
