@@ -88,7 +88,9 @@ constexpr int row_image_bytes() { return BM * row_pitch<BN>(); }
 
 // `add` (optional): a second [pixel][channel] view (pixel stride add_ld) whose values are added on the way out -- dst = [dst +]
 // tile + add (the shortcut gradient of a Bottleneck joins the data gradient of its first conv here instead of in a copy pass).
-template <int BM, int BN, int NW, typename T16, typename OffFn>
+// RG (rows per 64-row group, default 64 = every row): a tile whose row groups are only partly populated (conv_v4's shorter tail tiles) --
+// image row px holds output pixel m0 + (px >> 6) * RG + (px & 63) when (px & 63) < RG and nothing otherwise.
+template <int BM, int BN, int NW, typename T16, typename OffFn, int RG = 64>
 __device__ inline void store_rows(const char* smem, int lane, int wave, long m0, int n0, long M, int Cd, int accumulate, T16* dst, OffFn off,
                                   const T16* __restrict__ add = nullptr, long add_ld = 0) {
   constexpr int PT = row_pitch<BN>();
@@ -100,7 +102,8 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
 #pragma unroll 2
   for (int u = 0; u < ITERS; ++u) {
     const int px = PPI * (wave + NW * u) + pl;
-    const long m = m0 + px;
+    if (RG < 64 && (px & 63) >= RG) continue;
+    const long m = RG < 64 ? m0 + (px >> 6) * RG + (px & 63) : m0 + px;
 #pragma unroll
     for (int h = 0; h < HALVES; ++h) {
       const int c = 128 * h + 8 * chunk;

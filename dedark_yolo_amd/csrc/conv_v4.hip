@@ -59,6 +59,7 @@ struct P {
   long M;
   int nk;                        // K-steps = KH*KW*Cs/64
   int tiles_n, nblk;
+  int n_full, rb_tail;           // blocks [0, n_full) are 256-row tiles; the rest are tail tiles of 64 * rb_tail rows (see v4_launch)
   const char* add_src;           // optional addend view of a data gradient (dy_conv_desc.add_src)
   long add_src_ld;
 };
@@ -81,16 +82,17 @@ __device__ inline long dst_offset(const P& p, long m) {
 // ABL: compile-time ablation mask for tools/v4_diag (the library only instantiates ABL = 0): 1 no DMA inside the loop, 2 no MFMA,
 // 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores,
 // 128 no s_setprio around the MFMA clusters, 128 + 256 priority to the loading wave instead.
-template <int ABL, typename T = bf16_t>
-__global__ __launch_bounds__(512) void conv_kernel(const P p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// RB = 16-row blocks per wave and A-half: 4 = the full 256-row tile; 3 / 2 = TAIL tiles of 192 / 128 rows.  A tail tile keeps the
+// LDS layout and the DMA / phase schedule of the full tile, but only the first RG = 16 * RB rows of every 64-row group hold pixels
+// (LDS row r <-> tile row (r >> 6) * RG + (r & 63)); the other rows are fed by out-of-range DMAs (zeros, no traffic) and their MFMAs,
+// fragment reads and stores are not issued.  Why: 400 tiles on 256 CUs are two rounds with 44 % of the second one idle; cutting the last
+// 144 tiles' rows into 192 shorter tiles fills the CUs of that round with less work each (v4_launch picks the split).
+template <int ABL, typename T, int RB>
+__device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0, const int n0, const int tile_m) {
+  constexpr int RG = 16 * RB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int bid = xcd_remap(blockIdx.x, p.nblk);
-  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const long m0 = (long)tile_m * BM;
-  const int n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -103,8 +105,9 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
     const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
-      const bool ok = m0 + r < p.M;
+      const int rl = 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;       // LDS row
+      const int r = RB == 4 ? rl : (rl >> 6) * RG + (rl & 63);               // tile row
+      const bool ok = (RB == 4 || (rl & 63) < RG) && m0 + r < p.M;
       int img, oh, ow;
       walk.at(r, img, oh, ow);
       const int sh0 = oh * p.stride, sw0 = ow * p.stride;
@@ -175,16 +178,16 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   const int a_rd = (64 * wr + fr) * 128 + off0;          // + half base + 2048 * m-block ; k block 1: ^ 64
   const int b_rd = (32 * wc + fr) * 128 + off0;
 
-  f32x4 acc[2][2][4][2];
+  f32x4 acc[2][2][RB][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 afr[4][2], bfr[2][2][2];
+  u32x4 afr[RB][2], bfr[2][2][2];
 
   auto rd = [&](int byte) {
     if (ABL & 4) return u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   };
   auto read_a = [&](int buf, int h) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RB; ++i) {
       afr[i][0] = rd(buf * BUF + (h ? OFF_A1 : OFF_A0) + a_rd + 2048 * i);
       afr[i][1] = rd(buf * BUF + (h ? OFF_A1 : OFF_A0) + (a_rd ^ 64) + 2048 * i);
     }
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
+      for (int i = 0; i < RB; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
 #pragma unroll
       for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[bh][j][0])); asm volatile("" ::"v"(bfr[bh][j][1])); }
       mid();
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
@@ -273,7 +276,10 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
     __builtin_amdgcn_sched_barrier(0);
     if (!DMA_MID) { stage_a(b ^ 1, 1); advance(); }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B reads (issued first) are back: B-half 0 may be refilled in P2
+    // the four B reads (issued first) are back -- only the 2 * RB A reads may still be in flight: B-half 0 may be refilled in P2
+    if (RB == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if (RB == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp(0, 0);
     if (DMA_MID) mma(0, 0, [&]() { stage_a(b ^ 1, 1); advance(); });
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < RB; ++i) {
             const int px = 128 * ah + 64 * wr + 16 * i + cl;
             uint2 w2 = {dy_epi::pack2<T>(acc[ah][bh][i][j][0], acc[ah][bh][i][j][1]), dy_epi::pack2<T>(acc[ah][bh][i][j][2], acc[ah][bh][i][j][3])};
             *reinterpret_cast<uint2*>(smem + px * PT + c0 * 2) = w2;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < RB; ++i) {
             const int px = 128 * ah + 64 * wr + 16 * i + cl;
             float v[4];
 #pragma unroll
@@ -380,9 +386,10 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
       }
     }
   __syncthreads();
+  auto off_fn = [&](long m) { return dst_offset(p, m); };
   if (!(ABL & 64))
-    dy_epi::store_rows<BM, BN, 8>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst),
-                                  [&](long m) { return dst_offset(p, m); }, reinterpret_cast<const T*>(p.add_src), p.add_src_ld);
+    dy_epi::store_rows<BM, BN, 8, T, decltype(off_fn), RG>(smem, lane, wave, m0, n0, p.M, p.Cd, p.accumulate, reinterpret_cast<T*>(p.dst), off_fn,
+                                                           reinterpret_cast<const T*>(p.add_src), p.add_src_ld);
   if (p.stats && !(ABL & 512)) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);        // [2 (wr)][BN][2]
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
 #pragma unroll
           for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RB; ++i) {
               const float a = acc[ah][bh][i][j][e];
               s1 += a;
               s2 += a * a;
@@ -421,6 +428,24 @@ __global__ __launch_bounds__(512) void conv_kernel(const P p) {
         atomic_add_f64(st + p.Cd + n, (double)s2);
       }
     }
+  }
+}
+
+template <int ABL, typename T = bf16_t>
+__global__ __launch_bounds__(512) void conv_kernel(const P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // full tiles first (they are dispatched first), each population spread over the XCDs on its own
+  const bool tail = (int)blockIdx.x >= p.n_full;
+  const int bid = tail ? p.n_full + xcd_remap(blockIdx.x - p.n_full, p.nblk - p.n_full) : xcd_remap(blockIdx.x, p.n_full);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int n0 = tile_n * BN;
+  if (!tail) {
+    conv_tile<ABL, T, 4>(p, smem, (long)tile_m * BM, n0, tile_m);
+  } else {
+    const int full_m = p.n_full / p.tiles_n;
+    const long m0 = (long)full_m * BM + (long)(tile_m - full_m) * 64 * p.rb_tail;
+    if (p.rb_tail == 3) conv_tile<ABL, T, 3>(p, smem, m0, n0, tile_m);
+    else conv_tile<ABL, T, 2>(p, smem, m0, n0, tile_m);
   }
 }
 
@@ -455,6 +480,52 @@ bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode) {
   return !off && v4_variant(d, mode) != 0;
 }
 
+// Tile quantisation: T tiles on the chip's CUs (one block per CU) run in ceil(T / CUs) rounds, and a last round that is mostly empty
+// costs as much as a full one (256->256 at 40x40, batch 64: 400 tiles = 1.56 rounds -> 78 % at best).  The whole rounds keep 256-row
+// tiles; the rows of the last partial round are re-cut into tail tiles of 192 or 128 rows when that lets the round finish sooner.  The
+// relative cost of a tail tile (its B half of the K loop does not shrink) is measured, not guessed: tools/conv_bench, DESIGN.md section 4.
+static int v4_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+static void v4_split(long M, int tiles_n, int& n_full, int& rb_tail, int& nblk) {
+  const int cus = v4_cus();
+  const long tiles_m = (M + v4::BM - 1) / v4::BM;
+  const long T = tiles_m * tiles_n;
+  n_full = (int)T;
+  rb_tail = 4;
+  nblk = (int)T;
+  static const char* force = dy_env("DY_V4_TAIL");          // diagnostics builds: 0 = off, 2 / 3 = force that tail height
+  if (force && atoi(force) == 0) return;
+  if (T <= cus || T % cus == 0) return;
+  const long full_blocks = (T / cus) * cus;
+  const long full_m = full_blocks / tiles_n;                 // M-tiles of the whole rounds
+  if (full_m * tiles_n != full_blocks) return;
+  const long rows_left = M - full_m * v4::BM;
+  // cost of one round of tail tiles relative to a round of full tiles, measured (tools/gpu/v4_tail.sh, round 3: 256->256 3x3 at 40x40:
+  // 192-row round 62 us against 65.5; 128-row rounds 45 us; 512->512: 0.875 / 0.78).  The K loop is bound by LDS-DMA bytes, and a tail
+  // tile only sheds rows of the A half-tiles: (16 + 16 * RB / 4) / 32 of the bytes -> 0.875 / 0.75, which is what the clock shows.
+  const double cost[5] = {0, 0, 0.75, 0.92, 1.0};
+  double best = 1e9;
+  int best_rb = 4;
+  for (int rb = 4; rb >= 2; --rb) {
+    if (force && atoi(force) != rb && rb != 4) continue;
+    const long t = ((rows_left + 64 * rb - 1) / (64 * rb)) * tiles_n;
+    const double c = (double)((t + cus - 1) / cus) * cost[rb];
+    if (c < best - 1e-9) { best = c; best_rb = rb; }
+  }
+  if (force && atoi(force) >= 2 && atoi(force) <= 3) best_rb = atoi(force);
+  if (best_rb == 4) return;
+  n_full = (int)full_blocks;
+  rb_tail = best_rb;
+  nblk = (int)(full_blocks + ((rows_left + 64 * best_rb - 1) / (64 * best_rb)) * tiles_n);
+}
+
 template <int ABL, typename T = bf16_t>
 static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_variant = 0) {
   const int variant = force_variant ? force_variant : v4_variant(d, mode);
@@ -486,7 +557,7 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
   p.dst_row = d->dst_row_stride;
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
   p.tiles_n = dy_cdiv(d->Cd, variant);
-  p.nblk = dy_cdiv(p.M, v4::BM) * p.tiles_n;
+  v4_split(p.M, p.tiles_n, p.n_full, p.rb_tail, p.nblk);
   constexpr int EPI256 = dy_epi::row_image_bytes<256, 256>();
   constexpr int SH256 = 2 * v4::BUF > EPI256 ? 2 * v4::BUF : EPI256;
   static_assert(SH256 <= 160 * 1024, "LDS budget");
