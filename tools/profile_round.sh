@@ -8,6 +8,7 @@ OUT=$ROOT/${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 C2="--model yolov8n-lowlight.yaml --batch 32"
+C5="--imgsz 1280 --batch 16 --dtype fp16"
 STATS="--steps 10 --warmup 3 --no-cpu-baseline"
 SHORT="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -21,6 +22,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2_stats" -o c2 --
 step "PMC C3" &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/c3_f" -o f -- python3 "$ROOT/bench.py" $SHORT > "$OUT/pmc_c3_f.log" 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/c3_w" -o w -- python3 "$ROOT/bench.py" $SHORT > "$OUT/pmc_c3_w.log" 2>&1 &&
+step "kernel stats + PMC C5 (BASELINE configs[4]: the bandwidth-regime config, rocprof GB/s vs peak)" &&
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_stats" -o c5 -- python3 "$ROOT/bench.py" $C5 $STATS > "$OUT/bench_c5_under_rocprof.log" 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/c5_f" -o f -- python3 "$ROOT/bench.py" $C5 $SHORT > "$OUT/pmc_c5_f.log" 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/c5_w" -o w -- python3 "$ROOT/bench.py" $C5 $SHORT > "$OUT/pmc_c5_w.log" 2>&1 &&
+python3 "$ROOT/tools/pmc_traffic.py" $(find "$OUT/c5_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c5_w" -name "*counter_collection.csv" | head -1) "$OUT/c5_pmc_traffic.json" 5 > "$OUT/pmc_c5_summary.log" 2>&1 &&
+cp $(find "$OUT/c5_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c5_kernel_stats.csv" &&
+rm -rf "$OUT"/c5_stats "$OUT"/c5_f "$OUT"/c5_w &&
 step "PMC C2" &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/c2_f" -o f -- python3 "$ROOT/bench.py" $C2 $SHORT > "$OUT/pmc_c2_f.log" 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/c2_w" -o w -- python3 "$ROOT/bench.py" $C2 $SHORT > "$OUT/pmc_c2_w.log" 2>&1 &&
@@ -32,14 +40,16 @@ for shape in "256->256 @40" "128->128 @80" "256->256 @80" "64->64 @160" "512->51
 done &&
 cd "$ROOT" &&
 ( head -1 "$OUT"/sq_25625640.csv; for f in "$OUT"/sq_*.csv; do tail -n +2 "$f"; done ) > "$OUT/conv_mfma_util.csv" &&
-python3 tools/pmc_traffic.py $(find "$OUT/c2_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c2_w" -name "*counter_collection.csv" | head -1) "$OUT/c2_pmc_traffic.json" > "$OUT/pmc_c2_summary.log" 2>&1 &&
-python3 tools/pmc_traffic.py $(find "$OUT/c3_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c3_w" -name "*counter_collection.csv" | head -1) "$OUT/c3_pmc_traffic.json" > "$OUT/pmc_c3_summary.log" 2>&1 &&
+python3 tools/pmc_traffic.py $(find "$OUT/c2_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c2_w" -name "*counter_collection.csv" | head -1) "$OUT/c2_pmc_traffic.json" 5 > "$OUT/pmc_c2_summary.log" 2>&1 &&
+python3 tools/pmc_traffic.py $(find "$OUT/c3_f" -name "*counter_collection.csv" | head -1) $(find "$OUT/c3_w" -name "*counter_collection.csv" | head -1) "$OUT/c3_pmc_traffic.json" 5 > "$OUT/pmc_c3_summary.log" 2>&1 &&
 cp $(find "$OUT/c2_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c2_kernel_stats.csv" &&
 cp $(find "$OUT/c3_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c3_kernel_stats.csv" &&
 cp $(find "$OUT/c3s_stats" -name "*kernel_stats.csv" | head -1) "$OUT/c3_single_stream_kernel_stats.csv" &&
 rm -rf "$OUT"/c2_stats "$OUT"/c3_stats "$OUT"/c3s_stats "$OUT"/c2_f "$OUT"/c2_w "$OUT"/c3_f "$OUT"/c3_w "$OUT"/sq_*/ &&
-step "plain bench lines" &&
+step "plain bench lines (with this run's PMC summaries as their traffic source)" &&
+cp "$OUT/c3_pmc_traffic.json" profiles/r03_c3_pmc_traffic.json && cp "$OUT/c2_pmc_traffic.json" profiles/r03_c2_pmc_traffic.json &&
 python3 bench.py > "$OUT/bench_c3.json.log" 2> "$OUT/bench_c3.err" &&
-python3 bench.py $C2 --steps 100 --warmup 20 > "$OUT/bench_c2.json.log" 2> "$OUT/bench_c2.err"
+python3 bench.py $C2 --steps 100 --warmup 20 > "$OUT/bench_c2.json.log" 2> "$OUT/bench_c2.err" &&
+cp "$OUT/c5_pmc_traffic.json" profiles/r03_c5_pmc_traffic.json && python3 bench.py $C5 > "$OUT/bench_c5.json.log" 2> "$OUT/bench_c5.err"
 echo "profile_round exit $?"
 ls -la "$OUT"
