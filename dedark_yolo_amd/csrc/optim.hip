@@ -64,10 +64,14 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                              float* __restrict__ ema, const uint8_t* __restrict__ gid, Hyp h, float b1, float b2, float eps,
-                             float bc1, float bc2, float ed, const double* sumsq, float max_norm, float gscale,
+                             int step, float ed, const double* sumsq, float max_norm, float gscale,
                              const float* loss_scale, long n) {
   bool skip;
   const float cc = step_coef(sumsq, max_norm, loss_scale, &skip) * gscale;
+  // bias correction counts the steps the optimizer really TOOK: GradScaler.step does not call optimizer.step() after an overflow, so
+  // torch's Adam `step` does not advance there; loss_scale[2] = overflowed steps so far (dy_loss_scale_update)
+  const float eff = (float)(step - (loss_scale ? (int)loss_scale[2] : 0));
+  const float bc1 = 1.f - powf(b1, eff), bc2 = 1.f - powf(b2, eff);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     if (skip) {
       if (ema) ema[i] = ed * ema[i] + (1.f - ed) * p[i];
@@ -87,12 +91,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
-// dynamic loss scale (torch.cuda.amp.GradScaler.update: growth 2, backoff 0.5, growth_interval 2000): st = {scale, good steps}
+// dynamic loss scale (torch.cuda.amp.GradScaler.update: growth 2, backoff 0.5, growth_interval 2000):
+// st = {scale, consecutive finite steps, overflowed (skipped) steps in total}
 __global__ void loss_scale_update_kernel(float* st, const double* sumsq, float growth, float backoff, int interval) {
   if (threadIdx.x || blockIdx.x) return;
   if (!(*sumsq < (double)INFINITY)) {
     st[0] *= backoff;
     st[1] = 0.f;
+    st[2] += 1.f;
   } else {
     const float good = st[1] + 1.f;
     if (good >= (float)interval) {
@@ -153,9 +159,8 @@ extern "C" int dy_adamw_step_scaled(float* p, const float* g, float* exp_avg, fl
   DY_CHECK(p && g && exp_avg && exp_avg_sq && n >= 0 && step >= 1 && (!loss_scale || sumsq), "dy_adamw_step: bad args");
   if (n == 0) return 0;
   Hyp h = {{lr0, lr1, lr2, lr2}, {wd0, wd1, wd2, wd2}};
-  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  adamw_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, exp_avg, exp_avg_sq, ema, group_id, h, beta1, beta2, eps, bc1,
-                                                              bc2, ema_decay, sumsq, max_norm, grad_scale, loss_scale, n);
+  adamw_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, exp_avg, exp_avg_sq, ema, group_id, h, beta1, beta2, eps, step,
+                                                              ema_decay, sumsq, max_norm, grad_scale, loss_scale, n);
   DY_LAUNCH_CHECK();
   return 0;
 }

@@ -262,8 +262,8 @@ class DetectionTrainer:
         self.compute_dtype = (torch.bfloat16 if dt in ("bf16", "bfloat16") else
                               torch.float16 if dt in ("fp16", "float16", "half") else torch.float32)
         ops.set_compute_dtype(self.compute_dtype)
-        # fp16 = the reference's AMP (trainer.py:221 GradScaler): dynamic loss scale kept ON THE DEVICE, {scale, finite steps}
-        self.loss_scale = (torch.tensor([65536.0, 0.0], dtype=torch.float32, device=self.device)
+        # fp16 = the reference's AMP (trainer.py:221 GradScaler): dynamic loss scale kept ON THE DEVICE, {scale, finite steps, skipped steps}
+        self.loss_scale = (torch.tensor([65536.0, 0.0, 0.0], dtype=torch.float32, device=self.device)
                            if self.compute_dtype == torch.float16 else None)
         self.model = (model if model is not None else self.get_model(nc=nc)).to(self.device)
         self.model.args = self.args
@@ -523,8 +523,8 @@ class DetectionTrainer:
         self.step_count = int(dy_state.get("step_count", 0))
         self.last_opt_step = int(dy_state.get("last_opt_step", -1))
         ls = dy_state.get("loss_scale")
-        if ls is not None and getattr(self, "loss_scale", None) is not None:      # GradScaler state: {scale, finite steps so far}
-            self.loss_scale.copy_(torch.tensor(ls, dtype=torch.float32))
+        if ls is not None and getattr(self, "loss_scale", None) is not None:      # GradScaler state: {scale, finite steps so far, skipped}
+            self.loss_scale.copy_(torch.tensor((list(ls) + [0.0])[:3], dtype=torch.float32))
         ops.bump_weights_epoch()
         self.pack_plan.repack(self.model)
         return int(ck.epoch if ck.epoch is not None else -1) + 1

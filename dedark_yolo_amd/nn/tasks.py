@@ -219,8 +219,9 @@ class GraphPlan:
                 if j == 0 and getattr(mod, "_takes_into", False):
                     # fan-out: a later consumer already left a gradient for an input of this node -- the module adds into it (the
                     # data gradient of a Conv, the blend / pooling / resize adjoints of an ASFF level) and returns None for that input
-                    into = [grads[sidx] if (sidx >= 0 and torch.is_tensor(grads[sidx]) and grads[sidx].dim() == 4 and
-                                            grads[sidx].dtype == meta[0][1]) else None for sidx in src]
+                    # (only a gradient that is a dense NHWC tensor of exactly the producer's output shape qualifies: the modules add
+                    # through raw pointers; anything else takes the out-of-place sum below)
+                    into = [grads[sidx] if (sidx >= 0 and _accumulable(grads[sidx], st["metas"][sidx], meta[0][1])) else None for sidx in src]
                     if all(t is None for t in into):
                         into = None
                 gins = mod._bwd(tape, *gl, needs=needs, into=into) if into is not None else mod._bwd(tape, *gl, needs=needs)
@@ -265,6 +266,17 @@ class GraphPlan:
             for sidx in self.dead_after[i]:
                 outs[sidx] = None                     # last consumer done: the buffer goes back to the allocator now
         return outs[-1]
+
+
+def _accumulable(g, producer_metas, dtype):
+    """may a module add into gradient tensor `g` (left by another consumer of the same producer) through raw pointers?"""
+    if not (torch.is_tensor(g) and g.dim() == 4 and g.dtype == dtype):
+        return False
+    want = producer_metas[-1][0][0] if producer_metas else None          # output shape of the producer node's last module
+    if want is not None and tuple(g.shape) != tuple(want):
+        return False
+    st = g.stride()
+    return st[1] == 1 and st[3] >= g.shape[1] and st[2] == g.shape[3] * st[3] and st[0] == g.shape[2] * st[2]      # pixel-major view
 
 
 class _GraphFn(torch.autograd.Function):
@@ -360,9 +372,11 @@ class BaseModel(nn.Module):
             plan = self.__dict__["_plan"] = GraphPlan(list(self.model))
         eval_front = not self.training
         if _GRAPH_BACKWARD and self.training and torch.is_grad_enabled() and torch.is_tensor(x) and plan.trainable():
-            params = self.__dict__.get("_graph_params")
-            if params is None:
-                params = self.__dict__["_graph_params"] = tuple(p for p in self.model.parameters() if p.requires_grad)
+            sig = tuple(p.requires_grad for p in self.model.parameters())      # (un)freezing after train() must not go unnoticed
+            cached = self.__dict__.get("_graph_params")
+            if cached is None or cached[0] != sig:
+                cached = self.__dict__["_graph_params"] = (sig, tuple(p for p in self.model.parameters() if p.requires_grad))
+            params = cached[1]
             if params or x.requires_grad:
                 out = _GraphFn.apply(plan, (None, None), params, x, *params)
                 return list(out) if isinstance(out, tuple) else out

@@ -300,8 +300,10 @@ int dy_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, f
 /* fp16 training (reference AMP: torch.cuda.amp.GradScaler, U/engine/trainer.py:221,330,340,459-467).  The loss gradient is
  * multiplied by loss_scale[0] before the backward pass; the *_scaled steps divide it out again (clip on the TRUE norm), and leave
  * parameters and optimizer state untouched when *sumsq is inf / NaN (the EMA is still updated, as trainer.optimizer_step does).
- * dy_loss_scale_update then applies GradScaler.update to state = {scale, consecutive finite steps}: scale *= backoff after an
- * overflow, scale *= growth after `interval` finite steps.  loss_scale == NULL: exactly dy_sgd_step / dy_adamw_step. */
+ * dy_loss_scale_update then applies GradScaler.update to state = {scale, consecutive finite steps, overflowed steps in total} (three
+ * floats): scale *= backoff after an overflow, scale *= growth after `interval` finite steps.  dy_adamw_step_scaled takes its bias
+ * correction at step - state[2]: torch's Adam does not advance on the steps GradScaler skips.  loss_scale == NULL: exactly
+ * dy_sgd_step / dy_adamw_step. */
 int dy_sgd_step_scaled(float* p, const float* g, float* mom_buf, float* ema, const uint8_t* group_id, float lr0, float lr1, float lr2,
                        float wd0, float wd1, float wd2, float momentum, int nesterov, float ema_decay, const double* sumsq,
                        float max_norm, float grad_scale, const float* loss_scale, int64_t n, void* stream);

@@ -153,7 +153,7 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
         first, last = float(np.mean(losses[:10])), float(np.mean(losses[-10:]))
         assert last < 0.6 * first, (first, last)
         if dtype == "fp16":
-            scale, good = [float(v) for v in tr.loss_scale]
+            scale, good, _ = [float(v) for v in tr.loss_scale]
             assert np.isfinite(scale) and 1.0 <= scale <= 65536.0 and good >= 1, (scale, good)
     finally:
         dy.set_compute_dtype(torch.float32)
@@ -181,7 +181,7 @@ def test_fp16_loss_scale_follows_gradscaler():
         assert torch.equal(f.p, p0) and torch.equal(f.m, m0), "an overflowed step must not touch parameters / momentum"
         d = 0.9999 * (1 - math.exp(-tr.updates / 2000))
         assert torch.allclose(f.ema, d * e0 + (1 - d) * p0, rtol=1e-6, atol=1e-7)
-        assert [float(v) for v in tr.loss_scale] == [32768.0, 0.0]
+        assert [float(v) for v in tr.loss_scale] == [32768.0, 0.0, 1.0]
         # 2) finite step at scale 32768 == the unscaled step of the plain entry on a twin state
         f.g.copy_(g_true * 32768.0)
         twin_p, twin_m = f.p.clone(), f.m.clone()
@@ -192,12 +192,37 @@ def test_fp16_loss_scale_follows_gradscaler():
         tr.optimizer_step([0.01] * 3, 0.9)
         torch.cuda.synchronize()
         assert torch.allclose(f.p, twin_p, rtol=1e-5, atol=1e-8) and torch.allclose(f.m, twin_m, rtol=1e-5, atol=1e-8)
-        assert [float(v) for v in tr.loss_scale] == [32768.0, 1.0]
+        assert [float(v) for v in tr.loss_scale] == [32768.0, 1.0, 1.0]
         # 3) growth after `interval` finite steps (the update entry alone, interval 3)
-        st = torch.tensor([1024.0, 0.0], device="cuda")
-        for want in ([1024.0, 1.0], [1024.0, 2.0], [2048.0, 0.0]):
+        st = torch.tensor([1024.0, 0.0, 0.0], device="cuda")
+        for want in ([1024.0, 1.0, 0.0], [1024.0, 2.0, 0.0], [2048.0, 0.0, 0.0]):
             call("dy_loss_scale_update", ptr(st), ptr(ss), 2.0, 0.5, 3, stream())
             assert [float(v) for v in st] == want
+        # 4) AdamW: the bias correction does not advance on a skipped step (torch: scaler.step() leaves optimizer.step() uncalled)
+        n = 1024
+        gen2 = torch.Generator(device="cuda").manual_seed(6)
+        g1 = torch.randn(n, device="cuda", generator=gen2) * 1e-3
+        ref_p = torch.nn.Parameter(torch.ones(n, device="cuda"))
+        opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        p = torch.ones(n, device="cuda")
+        m1, m2 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ls = torch.tensor([4.0, 0.0, 0.0], device="cuda")
+        ssq = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for host_step, overflow in ((1, True), (2, False), (3, True), (4, False)):      # the HOST counter advances every time
+            gs = g1 * float(ls[0])
+            if overflow:
+                gs = gs.clone()
+                gs[3] = float("nan")
+            ssq.zero_()
+            call("dy_sumsq", ptr(gs), n, ptr(ssq), stream())
+            call("dy_adamw_step_scaled", ptr(p), ptr(gs), ptr(m1), ptr(m2), None, None, 1e-3, 1e-3, 1e-3, 0.0, 0.0, 0.0, 0.9, 0.999, 1e-8,
+                 host_step, 0.0, ptr(ssq), 1e9, 1.0, ptr(ls), n, stream())
+            call("dy_loss_scale_update", ptr(ls), ptr(ssq), 2.0, 0.5, 2000, stream())
+            if not overflow:
+                ref_p.grad = g1.clone()
+                opt.step()
+        torch.cuda.synchronize()
+        assert float(ls[2]) == 2.0 and torch.allclose(p, ref_p.detach(), rtol=1e-6, atol=1e-7)
     finally:
         dy.set_compute_dtype(torch.float32)
 

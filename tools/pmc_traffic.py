@@ -42,7 +42,35 @@ def load(path, counter):
     return agg
 
 
+_DEMANGLE = None
+
+
+def demangle(name):
+    """rocprofv3 leaves the _Float16 instantiations mangled (its demangler does not know DF16_); libstdc++'s does once the token is
+    spelled as the Itanium `half` (Dh): `v4::conv_kernel<0, half>` -> written back as `_Float16`."""
+    global _DEMANGLE
+    if not name.startswith("_Z"):
+        return name
+    if _DEMANGLE is None:
+        import ctypes
+        lib, libc = ctypes.CDLL("libstdc++.so.6"), ctypes.CDLL("libc.so.6")
+        lib.__cxa_demangle.restype = ctypes.c_void_p
+
+        def run(n):
+            st = ctypes.c_int(0)
+            p = lib.__cxa_demangle(n.encode(), None, None, ctypes.byref(st))
+            if not p:
+                return None
+            out = ctypes.string_at(p).decode()
+            libc.free(ctypes.c_void_p(p))
+            return out
+        _DEMANGLE = run
+    out = _DEMANGLE(name.replace("DF16_", "Dh"))
+    return name if out is None else re.sub(r"\bhalf\b", "_Float16", out)
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     return re.sub(r"^void ", "", name).split("(")[0]
 
