@@ -39,25 +39,28 @@ struct P {
   int N, H, W;
   int PW;          // padded pixels per row processed by the MFMAs (multiple of 16, >= W + 2)
   int XW;          // pixel slots per x row buffer (PW + 8): slot j holds padded column j - 1, i.e. image column j - 2
-  int rb, nseg;    // rows per block, blocks per image
+  int rb, nseg;    // rows per block, row segments per image
+  int SW, nstrip;  // column strips (images too wide for the LDS row buffers): strip width, strips per row segment; one strip = whole rows
   int co_stride;   // unused padding guard (kept zero)
   float* part;     // [co slices][blocks][9*CI][64]
 };
 
-// one image row -> one LDS row buffer; `shift` = slot index of image column 0 (2 for x, 1 for dz); rows outside the image and
-// slots outside [shift, shift + W) come from the zero page
+// one image row (or one column strip of it) -> one LDS row buffer; `shift` = slot index of image column col0 (2 for x, 1 for dz); rows
+// outside the image and image columns outside [lo, hi) come from the zero page.  x rows are loaded with one halo column on each side of
+// the strip (real neighbours, zeros only at the image border); dz rows with exactly the strip's columns, so that strips partition the sum.
 // C = channels per LDS pixel (64 or 128), NW = waves of the block, c0 = first channel fetched
 template <int C, int NW>
 __device__ inline void load_row(const char* src, long ld, int c0, int n, int h, int H, int W, char* buf, int slots, int shift, int wave,
-                                int lane, const char* zero) {
+                                int lane, const char* zero, int col0 = 0, int lo = 0, int hi = 1 << 30) {
+  if (hi > W) hi = W;
   constexpr int PPI = 512 / C;                          // pixels per wave instruction (1 KiB)
   constexpr int CPP = C / 8;                            // 16-byte chunks per pixel
   const int ninstr = slots / PPI;
   const bool rowok = h >= 0 && h < H;
   const int pl = lane / CPP, chunk = lane % CPP;
   for (int i = wave; i < ninstr; i += NW) {
-    const int w = PPI * i + pl - shift;
-    const char* g = (rowok && w >= 0 && w < W) ? src + ((((long)n * H + h) * W + w) * ld + c0 + chunk * 8) * 2 : zero;
+    const int w = col0 + PPI * i + pl - shift;
+    const char* g = (rowok && w >= lo && w < hi) ? src + ((((long)n * H + h) * W + w) * ld + c0 + chunk * 8) * 2 : zero;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + i * 1024), 16, 0, 0);
   }
 }
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   char* xring = smem;                                   // 4 x rows
   char* zring = smem + 4 * XB;                          // 2 dz rows
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
-  const int n = blockIdx.x / p.nseg, seg = blockIdx.x - n * p.nseg;
+  const int bseg = blockIdx.x / p.nstrip, strip = blockIdx.x - bseg * p.nstrip;
+  const int n = bseg / p.nseg, seg = bseg - n * p.nseg;
   const int h0 = seg * p.rb, h1 = min(h0 + p.rb, p.H);
+  const int col0 = strip * p.SW, xlo = max(col0 - 1, 0), xhi = col0 + p.SW + 1, zhi = col0 + p.SW;
 
   f32x16 acc[3][2];
 #pragma unroll
@@ -101,18 +106,18 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   const int b_off[2] = {lane_z, 64 + lane_z};
 
   // slot of image row r in the x ring: (r + 1) & 3
-  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0, p.H, p.W, xring + ((h0 + 1) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 + 1, p.H, p.W, xring + ((h0 + 2) & 3) * XB, p.XW, 2, wave, lane, zero);
-  load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h0, p.H, p.W, zring + (h0 & 1) * ZB, p.PW, 1, wave, lane, zero);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0, p.H, p.W, xring + ((h0 + 1) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
+  load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 + 1, p.H, p.W, xring + ((h0 + 2) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
+  load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h0, p.H, p.W, zring + (h0 & 1) * ZB, p.PW, 1, wave, lane, zero, col0, col0, zhi);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const int nslices = p.PW >> 4;
   for (int h = h0; h < h1; ++h) {
     if (h + 1 < h1) {                                    // prefetch what the next row needs
-      load_row<CI, NW>(p.x, p.x_ld, 0, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero);
-      load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero);
+      load_row<CI, NW>(p.x, p.x_ld, 0, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
+      load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero, col0, col0, zhi);
     }
     const char* xa[3];
 #pragma unroll
@@ -189,6 +194,17 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 
 }  // namespace wg3
 
+// column strips per row so that 4 x rows + 2 dz rows of one strip (+ halo) fit the 160 KiB of LDS; 0 = does not fit in <= 4 strips.
+// (1280x1280 inputs: 128 channels at W = 160 and 64 channels at W = 320 need two strips; everything at 640x640 takes whole rows)
+static int wg3_strips(int Wi, int Cin_pad) {
+  for (int ns = 1; ns <= 4; ++ns) {
+    const int SW = ((Wi + ns - 1) / ns + 15) / 16 * 16;
+    const int PW = (SW + 2 + 15) / 16 * 16;
+    if (4 * (PW + 8) * Cin_pad * 2 + 2 * PW * wg3::ZPB <= 160 * 1024) return ns;
+  }
+  return 0;
+}
+
 bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int N, int Hi, int Wi,
                           long x_ld, long dz_ld, long scratch_elems) {
   static const bool off = dy_env("DY_NO_WGRAD_V3") != nullptr;
@@ -197,11 +213,11 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
         pad == 1 && dil == 1))
     return false;
   if ((x_ld * 2) % 16 != 0 || (dz_ld * 2) % 16 != 0) return false;
-  const int PW = (Wi + 2 + 15) / 16 * 16;
-  if (4 * (PW + 8) * Cin_pad * 2 + 2 * PW * wg3::ZPB > 160 * 1024) return false;       // the six row buffers must fit LDS
+  if (wg3_strips(Wi, Cin_pad) == 0) return false;       // the six row buffers must fit LDS, in up to four column strips
   // worth it when the pixel loop is long enough to amortise the slab per block (64->64 at 40x40, B = 32 is not)
   static const long min_m = dy_env("DY_WG3_MINM") ? atol(dy_env("DY_WG3_MINM")) : 131072;
-  return (long)N * Hi * Wi >= min_m && scratch_elems >= (long)N * (Cout_pad / wg3::CO) * 9 * Cin_pad * wg3::CO;     // >= 1 block per image
+  return (long)N * Hi * Wi >= min_m &&
+         scratch_elems >= (long)N * wg3_strips(Wi, Cin_pad) * (Cout_pad / wg3::CO) * 9 * Cin_pad * wg3::CO;     // >= 1 block per image and strip
 }
 
 int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
@@ -210,7 +226,11 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   P p;
   p.x = (const char*)x; p.x_ld = x_ld; p.dz = (const char*)dz; p.dz_ld = dz_ld;
   p.N = N; p.H = Hi; p.W = Wi;
-  p.PW = (Wi + 2 + 15) / 16 * 16;
+  p.nstrip = wg3_strips(Wi, Cin_pad);
+  DY_CHECK(p.nstrip >= 1, "wgrad_v3: image rows too wide for the LDS row buffers");
+  p.SW = p.nstrip == 1 ? Wi : ((Wi + p.nstrip - 1) / p.nstrip + 15) / 16 * 16;
+  p.nstrip = (Wi + p.SW - 1) / p.SW;
+  p.PW = (p.SW + 2 + 15) / 16 * 16;
   p.XW = p.PW + 8;
   p.co_stride = 0;
   p.part = scratch;
@@ -221,13 +241,13 @@ int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_
   const long slab = (long)9 * Cin_pad * CO;
   const long maxblk = scratch_elems / (slab * ny);
   static const int target_blocks = dy_env("DY_WG3_BLOCKS") ? atoi(dy_env("DY_WG3_BLOCKS")) : 256;
-  int nseg = target_blocks / (N * ny);
-  if ((long)N * nseg > maxblk) nseg = (int)(maxblk / N);
+  int nseg = target_blocks / (N * ny * p.nstrip);
+  if ((long)N * nseg * p.nstrip > maxblk) nseg = (int)(maxblk / ((long)N * p.nstrip));
   if (nseg < 1) nseg = 1;
   if (nseg > Hi) nseg = Hi;
   p.rb = (Hi + nseg - 1) / nseg;
   p.nseg = (Hi + p.rb - 1) / p.rb;
-  const int nblk = N * p.nseg;
+  const int nblk = N * p.nseg * p.nstrip;
   DY_CHECK((long)nblk * ny * slab <= scratch_elems, "dy_conv2d_wgrad: scratch too small (%ld floats, need %ld)", scratch_elems,
            (long)nblk * ny * slab);
   const int shmem = 4 * p.XW * Cin_pad * 2 + 2 * p.PW * ZPB;

@@ -113,6 +113,10 @@ ROUTED = [
     ((8, 1024, 256, 48, 48, 1, 1, 0), (None, None, "wg4::wgrad_kernel")),                                       # pointwise variant
     ((16, 256, 64, 80, 80, 3, 1, 1), (None, None, "wg4::wgrad_kernel")),                                        # quarter-filled tile, long pixel loop
     ((12, 320, 128, 80, 80, 1, 1, 0), (None, None, "wg4::wgrad_kernel")),                                       # half-filled, K = 320 (2 tiles, 37 % pad)
+    # band weight gradient on rows too wide for its LDS row buffers (1280x1280 inputs, BASELINE configs[4]): two column strips with halo
+    ((6, 128, 128, 160, 160, 3, 1, 1), (None, None, "wg3::wgrad_kernel<128>")),
+    ((2, 64, 64, 320, 320, 3, 1, 1), (None, None, "wg3::wgrad_kernel<64>")),
+    ((6, 128, 128, 150, 171, 3, 1, 1), (None, None, "wg3::wgrad_kernel<128>")),                                  # ragged second strip
 ]
 
 
@@ -129,7 +133,7 @@ def test_conv_bf16_large_tile_routes(shape, want):
             assert routes.get(entry, "").startswith(sym), (entry, sym, routes)
 
 
-F16_SHAPES = GENERIC[:9] + PIPELINED[::3] + [r[0] for r in ROUTED[:10]]
+F16_SHAPES = GENERIC[:9] + PIPELINED[::3] + [r[0] for r in ROUTED[:10]] + [r[0] for r in ROUTED[-3:-1]]
 
 
 @pytest.mark.parametrize("shape", F16_SHAPES, ids=lambda s: "x".join(map(str, s)))
