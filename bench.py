@@ -295,7 +295,7 @@ def main():
     nc = 20
     torch.manual_seed(0)
     cfg = get_cfg(dict(model=args.model, dtype=args.dtype, optimizer="SGD", batch=args.batch * world, imgsz=args.imgsz,
-                       lowlight_FLAG=True, dedark_FLAG=True))
+                       lowlight_FLAG=True, dedark_FLAG=True, deterministic=False))       # throughput schedule: side streams on
     trainer = DetectionTrainer(cfg)
     trainer.setup(DetectionModel(args.model, nc=nc))
     batches = [synth_batch(1234 + 17 * rank + i, args.batch, args.imgsz, nc, device) for i in range(4)]
@@ -373,7 +373,7 @@ def main():
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"{wl}: {args.model}, {args.imgsz}x{args.imgsz}, "
                                     f"{args.dtype}, batch {args.batch}/GPU, nc={nc}, gamma~U(5,10), full train step "
-                                    "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), random-init weights, " +
+                                    "(preprocess+fwd+loss+assigner+bwd+clip+SGD+EMA), deterministic=False (side streams on), random-init weights, " +
                                     {"resident": "inputs resident in HBM",
                                      "device": "decoded dataset resident in HBM, mosaic/affine/HSV/flip rendered on the device every step",
                                      "host": "decoded dataset in pinned host memory: source images uploaded every step (PCIe-inclusive), "

@@ -274,8 +274,13 @@ class DetectionTrainer:
             for t in list(self.model.parameters()) + list(self.model.buffers()):       # K3: one broadcast of the start state
                 dist.broadcast(t.data, src=0)
         self.flat = FlatState(self.model, with_ema=True)
-        ops.enable_wgrad_stream(True)
-        ops.enable_branch_streams(True)
+        # `deterministic` (reference cfg/default.yaml:23, True by default there and here): one stream.  The side streams only change WHEN
+        # kernels run, but the f64-atomic BatchNorm sums then meet in a different order; on one stream a repeated step is bit-identical
+        # in every measurement taken here (tests/test_gpu_lowprec.py reports a run-to-run gradient change of exactly 0).  False = the
+        # throughput schedule: weight gradients and the coarser Detect levels on side streams (reproducible to f32 round-off).
+        det = bool(getattr(self.args, "deterministic", False))
+        ops.enable_wgrad_stream(not det)
+        ops.enable_branch_streams(not det)
         if self.world_size > 1:
             self.buckets = GradBuckets(self.flat, self.model)
         a = self.args

@@ -507,6 +507,10 @@ def enable_wgrad_stream(on=True):
     _wg_side.on = bool(on) and os.environ.get("DY_WGRAD_STREAM", "1") != "0"
 
 
+def wgrad_stream_enabled():
+    return bool(_wg_side.on)
+
+
 def wgrad_side_stream(device=None):
     s = _wg_side
     if not s.on:

@@ -508,3 +508,28 @@ def test_n_max_of_never_inherits_another_batch():
     assert n_max_of(b, 3) == 5                          # remembered for this object
     b[5] = 0                                            # in-place change bumps the version
     assert n_max_of(b, 3) == 6
+
+
+def test_deterministic_flag_gives_bit_identical_steps():
+    """args.deterministic (reference cfg/default.yaml:23, default True): the one-stream schedule.  Two trainers from the same start state
+    over the same three batches end with bit-identical parameters, momentum and EMA; deterministic=False switches the side streams on."""
+    import bench
+    from dedark_yolo_amd import ops
+
+    def run(det):
+        tr = _tiny_trainer("SGD", batch=64, dtype="bf16", deterministic=det)
+        assert ops.wgrad_stream_enabled() == (not det)
+        for i in range(3):
+            b = bench.synth_batch(40 + i, 4, 96, 20, "cuda")
+            tr.args.dark_param = b.pop("gamma")
+            b.pop("n_max", None)
+            tr.train_step(b, [0.01] * 3, 0.9)
+        torch.cuda.synchronize()
+        return tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.ema.clone()
+    try:
+        a, b = run(True), run(True)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        run(False)
+    finally:
+        import dedark_yolo_amd as dy
+        dy.set_compute_dtype(torch.float32)
