@@ -513,3 +513,32 @@ def test_graph_backward_is_one_autograd_node_and_matches_the_per_module_path(mon
     for k in a["grads"]:
         d = float((a["grads"][k] - b["grads"][k]).norm()) / max(float(b["grads"][k].norm()), 1e-30)
         assert d < (1e-4 if k.startswith("model.0.") else 2e-5), (k, d)      # the front-end's gradient has passed through the whole network
+
+
+@pytest.mark.parametrize("tag,name,nc", [("ori_t", "yolov8ori.yaml", 4), ("ll_t", "yolov8-lowlight.yaml", 20)])
+def test_product_eval_equals_the_reference_running_our_checkpoint(tag, name, nc):
+    """tests/golden/g12_ckpt_interop.npz: the REFERENCE's eval output after loading a last.pt written by this package
+    (attempt_load_one_weight, ultralytics/nn/tasks.py:674-707; produced in the build container by make_ckpt_interop.py).  The product
+    on the GPU, with the same fp16-rounded EMA weights and the same seeded input, must give the same decoded predictions."""
+    import dedark_yolo_amd as dy
+    from dedark_yolo_amd.nn.tasks import DetectionModel
+    from oracle import model as om
+    from parity_helpers import load_sd
+    from util import gold, load_yaml, rnd
+    g = gold("g12_ckpt_interop")
+    cfg = load_yaml(name)
+    cfg["scales"]["t"] = [0.33, 0.0625, 1024]
+    cfg["scale"] = "t"
+    dy.set_compute_dtype(torch.float32)
+    model = DetectionModel(cfg, nc=nc)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ema = om.rng_fill(shapes, 1202)                                   # what the script stored as the checkpoint's `ema`
+    load_sd(model, {k: (v.half().float() if v.is_floating_point() else v) for k, v in ema.items()})
+    model = model.cuda().eval()
+    x = rnd(int(g[f"{tag}_x_seed"]), 2, 3, 64, 64).pow(2.0)
+    with torch.no_grad():
+        y = model(x.cuda())
+    y = y[0] if isinstance(y, (list, tuple)) else y
+    want = g[f"{tag}_y"]
+    err = float((y.float().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+    assert y.shape == want.shape and err <= 1e-4, err
