@@ -14,16 +14,22 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
-__device__ inline float dot2(uint32_t a, uint32_t b, float c) {
+// two 16-bit MACs per lane and instruction, f32 accumulate: v_dot2c_f32_bf16 / v_dot2_f32_f16 (the reference's AMP dtype, BASELINE configs[4])
+template <typename T> __device__ inline float dot2(uint32_t a, uint32_t b, float c);
+template <> __device__ inline float dot2<bf16_t>(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
+template <> __device__ inline float dot2<f16_t>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+}
 
-template <int CS, int NCI>
-__global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __restrict__ dz, long dz_ld,
-                                                                const uint32_t* __restrict__ wt, bf16_t* __restrict__ dx,
+template <int CS, int NCI, typename T>
+__global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const T* __restrict__ dz, long dz_ld,
+                                                                const uint32_t* __restrict__ wt, T* __restrict__ dx,
                                                                 long dx_ld, int N, int Hd, int Wd, int Hs, int Ws,
-                                                                int accumulate, bf16_t* __restrict__ planar, int nplanes) {
+                                                                int accumulate, T* __restrict__ planar, int nplanes) {
   constexpr int NP = CS / 2;                         // packed pairs per pixel
   const int QH = (Hd + 1) >> 1, QW = (Wd + 1) >> 1;
   const long q = blockIdx.x * 256L + threadIdx.x;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
         const uint32_t* w = wt + ((ci * 3 + kh) * 3 + kw) * NP;       // wave-uniform -> s_load
         float s = acc[dh][dw][ci];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) s = dot2(P[a][b][p], w[p], s);
+        for (int p = 0; p < NP; ++p) s = dot2<T>(P[a][b][p], w[p], s);
         acc[dh][dw][ci] = s;
       }
 
@@ -81,13 +87,13 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
 #pragma unroll
       for (int ci = 0; ci < NCI; ++ci) {
         if (ci >= nplanes) break;
-        bf16_t* o = planar + (((long)n * nplanes + ci) * Hd + h) * Wd + 2 * qw;
+        T* o = planar + (((long)n * nplanes + ci) * Hd + h) * Wd + 2 * qw;
 #pragma unroll
         for (int dw = 0; dw < 2; ++dw)
           if (2 * qw + dw < Wd) {
             float v = acc[dh][dw][ci];
-            if (accumulate) v += bf16_to_f32(o[dw]);
-            o[dw] = f32_to_bf16(v);
+            if (accumulate) v += DT<T>::ld(o + dw);
+            DT<T>::st(o + dw, v);
           }
       }
     }
@@ -99,14 +105,14 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
     for (int dw = 0; dw < 2; ++dw) {
       const int h = 2 * qh + dh, w = 2 * qw + dw;
       if (h < Hd && w < Wd) {
-        bf16_t* o = dx + (((long)n * Hd + h) * Wd + w) * dx_ld;
+        T* o = dx + (((long)n * Hd + h) * Wd + w) * dx_ld;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (accumulate) ldvec<bf16_t>(o, v);
+        if (accumulate) ldvec<T>(o, v);
 #pragma unroll
         for (int ci = 0; ci < NCI; ++ci) v[ci] += acc[dh][dw][ci];
-        stvec<bf16_t>(o, v);
+        stvec<T>(o, v);
       }
     }
 }
@@ -115,8 +121,9 @@ __global__ __launch_bounds__(256) void dgrad3x3s2_small_kernel(const bf16_t* __r
 // ultralytics/nn/modules/block.py:47-52:  dx[m][ci] (+)= sum_{co<8} dz[m][co] * w[co][ci].  Pure write bandwidth; the MFMA
 // tile kernel spent 525 us on 64x80x80x256 (K = 8 of a 64-wide step, 2-byte stores), this one moves 16 B per lane.
 constexpr int THIN_PX = 4;
-__global__ __launch_bounds__(256) void dgrad1x1_thin_kernel(const bf16_t* __restrict__ dz, long dz_ld, const bf16_t* __restrict__ wt,
-                                                             bf16_t* __restrict__ dx, long dx_ld, long M, int Cd, int accumulate) {
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad1x1_thin_kernel(const T* __restrict__ dz, long dz_ld, const T* __restrict__ wt,
+                                                             T* __restrict__ dx, long dx_ld, long M, int Cd, int accumulate) {
   const int CG = Cd >> 3;
   const long t = blockIdx.x * 256L + threadIdx.x;
   const int cg = (int)(t % CG);
@@ -130,32 +137,32 @@ __global__ __launch_bounds__(256) void dgrad1x1_thin_kernel(const bf16_t* __rest
     const long m = m0 + px;
     if (m >= M) break;
     const u32x4 z = *reinterpret_cast<const u32x4*>(dz + m * dz_ld);
-    bf16_t* o = dx + m * dx_ld + cg * 8;
+    T* o = dx + m * dx_ld + cg * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (accumulate) ldvec<bf16_t>(o, v);
+    if (accumulate) ldvec<T>(o, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float s = v[e];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s = dot2(z[q], w[e][q], s);
+      for (int q = 0; q < 4; ++q) s = dot2<T>(z[q], w[e][q], s);
       v[e] = s;
     }
-    stvec<bf16_t>(o, v);
+    stvec<T>(o, v);
   }
 }
 
-template <int CS>
+template <int CS, typename T>
 int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
   const long quads = (long)d->N * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
   const unsigned grid = (unsigned)((quads + 255) / 256);
   const int nci = d->dst_valid_channels > 0 && d->dst_valid_channels <= 4 ? 4 : 8;
   dy_note_kernel("dgrad3x3s2_small_kernel");
 #define GO(NCI)                                                                                                              \
-  dgrad3x3s2_small_kernel<CS, NCI><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const uint32_t*)d->w, (bf16_t*)d->dst, \
-                                                         d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate,        \
-                                                         (bf16_t*)d->dst_planar, d->dst_valid_channels)
+  dgrad3x3s2_small_kernel<CS, NCI, T><<<grid, 256, 0, st>>>((const T*)d->src, d->src_ld, (const uint32_t*)d->w, (T*)d->dst,       \
+                                                            d->dst_ld, d->N, d->Hd, d->Wd, d->Hs, d->Ws, d->accumulate,         \
+                                                            (T*)d->dst_planar, d->dst_valid_channels)
   if (nci == 4) GO(4); else GO(8);
 #undef GO
   DY_LAUNCH_CHECK();
@@ -165,7 +172,7 @@ int launch_small_dgrad(const dy_conv_desc* d, hipStream_t st) {
 }  // namespace
 
 static bool thin_eligible(const dy_conv_desc* d) {
-  return d->dtype == DY_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cs == 8 && d->Cd % 8 == 0 &&
+  return (d->dtype == DY_BF16 || d->dtype == DY_F16) && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cs == 8 && d->Cd % 8 == 0 &&
          d->KHf == 0 && d->dst_row_stride == 0 && d->dst && !d->dst_planar && (d->src_ld * 2) % 16 == 0 && (d->dst_ld * 2) % 16 == 0 &&
          d->Hs == d->Hd && d->Ws == d->Wd;
 }
@@ -174,7 +181,7 @@ bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d) {
   static const bool off = dy_env("DY_NO_CONV_SMALL") != nullptr;
   if (off) return false;
   if (thin_eligible(d)) return true;
-  return d->dtype == DY_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1 && d->Cd == 8 &&
+  return (d->dtype == DY_BF16 || d->dtype == DY_F16) && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1 && d->Cd == 8 &&
          (d->Cs == 16 || d->Cs == 32 || d->Cs == 64) && d->KHf == 0 && d->dst_row_stride == 0 && (d->src_ld * 2) % 16 == 0 &&
          ((d->dst_planar && d->dst_valid_channels > 0 && d->dst_valid_channels <= 8) || (d->dst && (d->dst_ld * 2) % 16 == 0));
 }
@@ -185,12 +192,22 @@ int dy_conv_small_dgrad_launch(const dy_conv_desc* d, void* stream) {
     const long M = (long)d->N * d->Hd * d->Wd;
     const long threads = (M + THIN_PX - 1) / THIN_PX * (d->Cd / 8);
     dy_note_kernel("dgrad1x1_thin_kernel");
-    dgrad1x1_thin_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const bf16_t*)d->w,
-                                                                           (bf16_t*)d->dst, d->dst_ld, M, d->Cd, d->accumulate);
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (d->dtype == DY_F16)
+      dgrad1x1_thin_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)d->src, d->src_ld, (const f16_t*)d->w, (f16_t*)d->dst, d->dst_ld, M, d->Cd,
+                                                        d->accumulate);
+    else
+      dgrad1x1_thin_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)d->src, d->src_ld, (const bf16_t*)d->w, (bf16_t*)d->dst, d->dst_ld, M,
+                                                         d->Cd, d->accumulate);
     DY_LAUNCH_CHECK();
     return 0;
   }
-  if (d->Cs == 16) return launch_small_dgrad<16>(d, st);
-  if (d->Cs == 32) return launch_small_dgrad<32>(d, st);
-  return launch_small_dgrad<64>(d, st);
+  if (d->dtype == DY_F16) {
+    if (d->Cs == 16) return launch_small_dgrad<16, f16_t>(d, st);
+    if (d->Cs == 32) return launch_small_dgrad<32, f16_t>(d, st);
+    return launch_small_dgrad<64, f16_t>(d, st);
+  }
+  if (d->Cs == 16) return launch_small_dgrad<16, bf16_t>(d, st);
+  if (d->Cs == 32) return launch_small_dgrad<32, bf16_t>(d, st);
+  return launch_small_dgrad<64, bf16_t>(d, st);
 }

@@ -694,7 +694,7 @@ def conv_backward(tape, dy, need_dx=True, dx_out=None, accumulate=False, add_src
     wt = _pack(ctx.weight, cout_pad, cin_pad, True, dtype)
     # network stem (3 -> c, 3x3 stride 2): the direct kernel writes dx planar [B,Cin,H,W], the layout the front-end's
     # backward consumes (6 B/pixel instead of a 16 B NHWC8 vector that is 5/8 padding)
-    planar = (dx_out is None and add_src is None and dtype == torch.bfloat16 and cin_pad == 8 and Cin <= 4 and (KH, KW) == (3, 3) and ctx.stride == 2
+    planar = (dx_out is None and add_src is None and dtype in (torch.bfloat16, torch.float16) and cin_pad == 8 and Cin <= 4 and (KH, KW) == (3, 3) and ctx.stride == 2
               and ctx.pad == 1 and ctx.dil == 1 and cout_pad in (16, 32, 64) and os.environ.get("DY_NO_CONV_SMALL") is None)
     if planar:
         dxp = torch.empty((B, Cin, H, W), dtype=dtype, device=dev)

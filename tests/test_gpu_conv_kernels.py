@@ -133,7 +133,9 @@ def test_conv_bf16_large_tile_routes(shape, want):
             assert routes.get(entry, "").startswith(sym), (entry, sym, routes)
 
 
-F16_SHAPES = GENERIC[:9] + PIPELINED[::3] + [r[0] for r in ROUTED[:10]] + [r[0] for r in ROUTED[-3:-1]]
+# + the direct dot2 kernels in f16 (v_dot2_f32_f16): thin 1x1 dgrad, stem dgrad with planar dx
+F16_SHAPES = GENERIC[:9] + PIPELINED[::3] + [r[0] for r in ROUTED[:10]] + [r[0] for r in ROUTED[-3:-1]] + [
+    (3, 256, 8, 37, 23, 1, 1, 0), (2, 3, 16, 64, 64, 3, 2, 1), (2, 3, 64, 33, 47, 3, 2, 1)]
 
 
 @pytest.mark.parametrize("shape", F16_SHAPES, ids=lambda s: "x".join(map(str, s)))
