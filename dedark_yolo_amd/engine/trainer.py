@@ -274,10 +274,10 @@ class DetectionTrainer:
             for t in list(self.model.parameters()) + list(self.model.buffers()):       # K3: one broadcast of the start state
                 dist.broadcast(t.data, src=0)
         self.flat = FlatState(self.model, with_ema=True)
-        # `deterministic` (reference cfg/default.yaml:23, True by default there and here): one stream.  The side streams only change WHEN
-        # kernels run, but the f64-atomic BatchNorm sums then meet in a different order; on one stream a repeated step is bit-identical
-        # in every measurement taken here (tests/test_gpu_lowprec.py reports a run-to-run gradient change of exactly 0).  False = the
-        # throughput schedule: weight gradients and the coarser Detect levels on side streams (reproducible to f32 round-off).
+        # `deterministic` (reference cfg/default.yaml:23, True by default there and here): one stream, kernels in program order.  What
+        # stays free is the arrival order of the f64 atomics behind the BatchNorm / loss sums (last-bit effects on the f32 statistics):
+        # repeated runs agree to f32 round-off, not bit for bit (tests/test_gpu_trainer.py measures it).  False = the throughput
+        # schedule: weight gradients and the coarser Detect levels on side streams.
         det = bool(getattr(self.args, "deterministic", False))
         ops.enable_wgrad_stream(not det)
         ops.enable_branch_streams(not det)
