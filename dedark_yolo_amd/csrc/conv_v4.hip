@@ -126,23 +126,33 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
       b_off[i] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
     }
   }
-  // K-step whose half-tiles are being issued (all wave-uniform)
-  int sk = 0, s_th = 0, s_tw = 0, s_ci = 0, s_bit = 0;
-  int a_koff = (p.dh0 * p.Ws + p.dw0) * (int)p.src_ld * 2;
-  unsigned b_koff = (unsigned)(((long)(p.kh0 * p.KWf + p.kw0)) * p.Cs * 2);
+  // K-step whose half-tiles are being issued (all wave-uniform).  K order: all taps of one BK-channel chunk, then the next chunk.  The
+  // taps re-read the SAME pixels (shifted windows), so with the taps innermost a tile's live set is (tile + halo) x BK channels (~40 KB;
+  // 32 CUs x 40 KB sit in an XCD's 4 MiB L2) and the 2nd .. 9th reads are L2 hits; tap-major order cycled through the tile's full
+  // channel depth between two reads of a line (150 KB per CU: more than its L2 share -> every tap went back to the Infinity Cache,
+  // 2.4x fabric traffic).
+  // The per-tap byte offsets sit in one VGPR each (lane t = tap t <= 25) and advance() picks them with v_readlane: the walk used to
+  // recompute them with a dozen dependent s_mul / s_add and two branches per K-step, inside P1's load part that the partner group's
+  // MFMA cluster waits for (s_memtime stamps, tools/v4_diag: P1 ran ~280 cycles longer than P3, which issues the same reads and DMA).
+  const int ntaps = p.KH * p.KW;
+  int vtap_a, vtap_b;
+  {
+    const int t = lane < ntaps ? lane : 0;
+    const int th = t / p.KW, tw = t - th * p.KW;
+    vtap_a = ((p.dh0 + p.dhs * th) * p.Ws + p.dw0 + p.dws * tw) * (int)p.src_ld * 2;
+    vtap_b = (int)((((long)((p.kh0 + p.khs * th) * p.KWf + p.kw0 + p.kws * tw)) * p.Cs) * 2);
+  }
+  int sk = 0, s_tap = 0, s_ci2 = 0, s_bit = 0;
+  int a_koff = __builtin_amdgcn_readlane(vtap_a, 0);
+  unsigned b_koff = (unsigned)__builtin_amdgcn_readlane(vtap_b, 0);
   auto advance = [&]() {
     ++sk;
-    // K order: all taps of one BK-channel chunk, then the next chunk.  The taps re-read the SAME pixels (shifted windows), so with
-    // the taps innermost a tile's live set is (tile + halo) x BK channels (~40 KB; 32 CUs x 40 KB sit in an XCD's 4 MiB L2) and
-    // the 2nd .. 9th reads are L2 hits; tap-major order cycled through the tile's full channel depth between two reads of a
-    // line (150 KB per CU: more than its L2 share -> every tap went back to the Infinity Cache, 2.4x fabric traffic).
-    ++s_bit;
-    if (++s_tw == p.KW) {
-      s_tw = 0;
-      if (++s_th == p.KH) { s_th = 0; s_bit = 0; s_ci += BK; }
-    }
-    a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2 + s_ci * 2;
-    b_koff = (unsigned)((((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs + s_ci) * 2);
+    const bool wrap = s_tap + 1 == ntaps;
+    s_tap = wrap ? 0 : s_tap + 1;
+    s_ci2 += wrap ? 2 * BK : 0;
+    a_koff = __builtin_amdgcn_readlane(vtap_a, s_tap) + s_ci2;
+    b_koff = (unsigned)(__builtin_amdgcn_readlane(vtap_b, s_tap) + s_ci2);
+    s_bit = s_tap;               // bit th * KW + tw of the window masks
     if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a buffer nobody reads again)
       s_bit = 31;
       b_koff = 0x80000000u;
@@ -200,16 +210,19 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
       afr[i][1] = rd(buf * BUF + (h ? OFF_A1 : OFF_A0) + (a_rd ^ 64) + 2048 * i);
     }
   };
-  auto read_b = [&](int buf, int h) {
+  // `rs` = register set the fragments go to.  The two sets swap roles every K-step: in a K-step of parity b, B-half 0 lives in set b and
+  // B-half 1 in set b ^ 1 -- so that P4, whose MFMAs use half 0 only, can already read half 0 of the NEXT K-step into the set half 1 has
+  // just vacated (see kstep: the load parts then carry 8 / 4 / 8 / 4 fragment reads instead of 12 / 4 / 8 / 0)
+  auto read_b = [&](int buf, int h, int rs) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bfr[h][j][0] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + b_rd + 2048 * j);
-      bfr[h][j][1] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + (b_rd ^ 64) + 2048 * j);
+      bfr[rs][j][0] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + b_rd + 2048 * j);
+      bfr[rs][j][1] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + (b_rd ^ 64) + 2048 * j);
     }
   };
   // `mid` runs between the two k-halves of the cluster: with ABL & 1024 the phase's DMA is issued there (experiment: the DMA issue
   // then waits on this wave's own matrix pipe instead of lengthening the load part the partner wave is waiting for)
-  auto mma = [&](int ah, int bh, auto mid) {
+  auto mma = [&](int ah, int bh, int rs, auto mid) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL & 256) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +230,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
 #pragma unroll
       for (int i = 0; i < RB; ++i) { asm volatile("" ::"v"(afr[i][0])); asm volatile("" ::"v"(afr[i][1])); }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[bh][j][0])); asm volatile("" ::"v"(bfr[bh][j][1])); }
+      for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[rs][j][0])); asm volatile("" ::"v"(bfr[rs][j][1])); }
       mid();
       return;
     }
@@ -229,7 +242,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
-          acc[ah][bh][i][j] = mfma_16x16x32<T>(bfr[bh][j][kb], afr[i][kb], acc[ah][bh][i][j]);
+          acc[ah][bh][i][j] = mfma_16x16x32<T>(bfr[rs][j][kb], afr[i][kb], acc[ah][bh][i][j]);
       if (kb == 0) {
         __builtin_amdgcn_sched_barrier(0);
         mid();
@@ -249,6 +262,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
   stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  read_b(0, 0, 0);                                                   // B-half 0 of K-step 0 (later ones are read in P4 of the step before)
   if (!(ABL & 8) && wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
   in_loop = true;
 
@@ -270,32 +284,26 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     constexpr int b = decltype(bufc)::value;
     // P1
     stamp(3, 2);                                   // (closes the previous phase: second barrier of P4)
-    read_b(b, 0);
-    __builtin_amdgcn_sched_barrier(0);
     read_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (!DMA_MID) { stage_a(b ^ 1, 1); advance(); }
     __builtin_amdgcn_sched_barrier(0);
-    // the four B reads (issued first) are back -- only the 2 * RB A reads may still be in flight: B-half 0 may be refilled in P2
-    if (RB == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    else if (RB == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp(0, 0);
-    if (DMA_MID) mma(0, 0, [&]() { stage_a(b ^ 1, 1); advance(); });
-    else mma(0, 0, nothing);
+    if (DMA_MID) mma(0, 0, b, [&]() { stage_a(b ^ 1, 1); advance(); });
+    else mma(0, 0, b, nothing);
     stamp(0, 1);
     __builtin_amdgcn_s_barrier();
     // P2
     stamp(0, 2);
-    read_b(b, 1);
+    read_b(b, 1, b ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA_MID) stage_b(b, 0);
+    if (!DMA_MID) stage_b(b, 0);                   // B-half 0 of this buffer was read in P4 of the previous K-step: free since then
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     stamp(1, 0);
-    if (DMA_MID) mma(0, 1, [&]() { stage_b(b, 0); });
-    else mma(0, 1, nothing);
+    if (DMA_MID) mma(0, 1, b ^ 1, [&]() { stage_b(b, 0); });
+    else mma(0, 1, b ^ 1, nothing);
     stamp(1, 1);
     __builtin_amdgcn_s_barrier();
     // P3
@@ -304,14 +312,21 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     __builtin_amdgcn_sched_barrier(0);
     if (!DMA_MID) stage_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
+    // B-half 0 of K-step k+1 (issued in P2 of K-step k-1) has landed for this wave: everything but the 10 youngest pieces
+    // (A0 / B1 / A1 of k+1, B0 / A0 of k+2; DMA_MID: 8, this phase's refill comes later).  Behind this phase's barriers all waves
+    // have been here, so P4 may read it.
+    if (DMA_MID) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp(2, 0);
-    if (DMA_MID) mma(1, 1, [&]() { stage_a(b, 0); });
-    else mma(1, 1, nothing);
+    if (DMA_MID) mma(1, 1, b ^ 1, [&]() { stage_a(b, 0); });
+    else mma(1, 1, b ^ 1, nothing);
     stamp(2, 1);
     __builtin_amdgcn_s_barrier();
     // P4
     stamp(2, 2);
+    read_b(b ^ 1, 0, b ^ 1);                       // next K-step's B-half 0 into the register set B-half 1 has just vacated
+    __builtin_amdgcn_sched_barrier(0);
     if (!DMA_MID) stage_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
     // everything but the three youngest half-tiles: K-step k+1 is complete (DMA_MID: this phase's refill is issued after the wait,
@@ -320,8 +335,8 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp(3, 0);
-    if (DMA_MID) mma(1, 0, [&]() { stage_b(b, 1); });
-    else mma(1, 0, nothing);
+    if (DMA_MID) mma(1, 0, b, [&]() { stage_b(b, 1); });
+    else mma(1, 0, b, nothing);
     stamp(3, 1);
     __builtin_amdgcn_s_barrier();
   };
