@@ -293,14 +293,14 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     if (DMA_MID) mma(0, 0, b, [&]() { stage_a(b ^ 1, 1); advance(); });
     else mma(0, 0, b, nothing);
     stamp(0, 1);
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     // P2
     stamp(0, 2);
     read_b(b, 1, b ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     if (!DMA_MID) stage_b(b, 0);                   // B-half 0 of this buffer was read in P4 of the previous K-step: free since then
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     stamp(1, 0);
     if (DMA_MID) mma(0, 1, b ^ 1, [&]() { stage_b(b, 0); });
     else mma(0, 1, b ^ 1, nothing);
@@ -322,7 +322,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     if (DMA_MID) mma(1, 1, b ^ 1, [&]() { stage_a(b, 0); });
     else mma(1, 1, b ^ 1, nothing);
     stamp(2, 1);
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     // P4
     stamp(2, 2);
     read_b(b ^ 1, 0, b ^ 1);                       // next K-step's B-half 0 into the register set B-half 1 has just vacated
@@ -333,7 +333,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     // so only TWO half-tiles are younger than K-step k+1's last one)
     if (DMA_MID) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     stamp(3, 0);
     if (DMA_MID) mma(1, 0, b, [&]() { stage_b(b, 1); });
     else mma(1, 0, b, nothing);

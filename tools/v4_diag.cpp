@@ -67,6 +67,8 @@ int main(int argc, char** argv) {
     run<1024>("DMA inside the MFMA clusters (again)", f, flops, st, it);
   }
   run<1 | 4>("MFMA + barriers only", f, flops, st, it);
+  run<1 | 4 | 2048>("MFMA + HALF the barriers (phases merged in pairs; timing only)", f, flops, st, it);
+  run<2048>("everything, phases merged in pairs (WRONG results; timing only)", f, flops, st, it);
   run<1 | 2>("LDS reads + barriers only", f, flops, st, it);
   run<2 | 4>("DMA + barriers only", f, flops, st, it);
   run<1 | 2 | 4>("barriers + scalar bookkeeping only", f, flops, st, it);
