@@ -203,7 +203,10 @@ def train_labels(plan, labels, shapes):
         h, w = shapes[src]
         b = _xywh2xyxy(np.array(labels[src]["bboxes"], dtype=F32, copy=True).reshape(-1, 4))
         _mul(b, w, h)
-        padw, padh = rect[0] - rect[4], rect[1] - rect[5]
+        if plan.mosaic:
+            padw, padh = rect[0] - rect[4], rect[1] - rect[5]           # Mosaic._update_labels: integer paste offset (augment.py:189-192)
+        else:
+            padw, padh = plan.letterbox.dw, plan.letterbox.dh          # LetterBox._update_labels: the UNROUNDED half padding (:593-603)
         b[:, 0] += padw
         b[:, 1] += padh
         b[:, 2] += padw

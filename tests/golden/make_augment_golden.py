@@ -218,6 +218,7 @@ def main():
     out = {}
     for tag, res in (("t0", run_train(1301, 64, 6, [0, 3, 5, 1])),
                      ("t1", run_train(1302, 96, 5, [4, 2, 2], degrees=10.0, shear=2.0, flipud=0.5, translate=0.2, scale=0.3)),
+                     ("t2", run_train(1305, 64, 6, [0, 1, 2, 3, 4], mosaic=0.0, degrees=5.0)),     # Mosaic's coin fails: LetterBox pre_transform path
                      ("val", run_val(1303, 64, [(48, 64), (64, 40), (64, 64), (30, 50)])),
                      ("dark", run_dark(1304))):
         for k, v in res.items():
