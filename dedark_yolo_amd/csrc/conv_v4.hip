@@ -15,9 +15,14 @@
 //     P1: A-half 1 of step k+1,  P2: B-half 0,  P3: A-half 0,  P4: B-half 1 of step k+2;
 //   * the DMA is never drained inside the loop: one s_waitcnt vmcnt(6) per K-step (in P4, before its barrier) leaves the three
 //     youngest half-tiles in flight across the barriers; a buffer is read from the phase AFTER the wait that retires it;
-//   * the implicit-GEMM gather costs 5 VALU per DMA: every lane keeps a 32-bit byte offset of its output pixel and a bit mask of
-//     the window taps that fall inside the image; padding taps, rows beyond M, channels beyond Cd and K-steps beyond the last
-//     one use an offset outside the buffer descriptor, for which the hardware writes zeros (no zero page, no branches);
+//   * the implicit-GEMM gather costs ONE VALU per activation DMA and none per weight DMA: every lane keeps the 32-bit byte offset of
+//     its output pixel (the instruction's VGPR offset, constant over the K loop); the window tap and channel chunk of the K-step are
+//     wave-uniform and travel in the instruction's SGPR offset; a per-lane word of "tap t is padding" bits is rotated once per K-step
+//     (inside the MFMA cluster, where a VALU slot is free) so that the current tap's bit sits in bit 31 and one v_and_or puts it on top
+//     of the offset: padding taps, rows beyond M and channels beyond Cd then lie outside the buffer descriptor, for which the hardware
+//     writes zeros (no zero page, no branches); K-steps beyond the last one use a descriptor of zero records.  (The first version
+//     spent 4 dependent VALU per activation piece and 1 per weight piece in the load part of a phase -- next to the partner wave's
+//     MFMA cluster, where a VALU instruction of the other wave waits ~16 cycles for an issue slot.)
 //   * LDS rows are 128 bytes (64 bf16) with the 16-byte slot XOR-ed by (row>>1)&7 on the DMA source side and on the read side:
 //     the 16-lane groups of ds_read_b128 hit 16 different slots of the 256-byte bank row for the 16x16x32 operand layout.
 // Epilogue as in conv_epilogue.h (transposed bf16 image, ds_read_b64_tr_b16, 16-byte stores, BatchNorm sums), written for the
@@ -33,7 +38,7 @@ namespace v4 {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 128 * 128;                     // one half-tile: 128 rows x 64 bf16
 constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF, BUF = 4 * HALF;
-constexpr unsigned A_OOB = 0x80000000u;             // > any source extent (checked by the dispatcher: <= 2 GiB)
+// bit 31 of an activation offset marks a padded lane: beyond any source extent (checked by the dispatcher: < 2 GiB)
 constexpr unsigned B_ROW_OOB = 0x40000000u;         // weight extent <= 1 GiB: row-invalid + any k offset stays out of range
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -57,6 +62,8 @@ struct P {
   double* stats;
   int accumulate;
   long M;
+  int a_min;                     // most negative window-tap byte offset (<= 0): folded into the activation descriptor's base so that
+                                 // the per-K-step SGPR offsets are >= 0
   int nk;                        // K-steps = KH*KW*Cs/64
   int tiles_n, nblk;
   int n_full, rb_tail;           // blocks [0, n_full) are 256-row tiles; the rest are tail tiles of 64 * rb_tail rows (see v4_launch)
@@ -81,7 +88,7 @@ __device__ inline long dst_offset(const P& p, long m) {
 
 // ABL: compile-time ablation mask for tools/v4_diag (the library only instantiates ABL = 0): 1 no DMA inside the loop, 2 no MFMA,
 // 4 no LDS fragment reads, 8 no stagger between the wave groups, 16 no A-side DMA, 32 no B-side DMA, 64 no epilogue stores,
-// 128 no s_setprio around the MFMA clusters, 128 + 256 priority to the loading wave instead.
+// 128 no s_setprio around the MFMA clusters, 128 + 256 priority to the loading wave instead, 2048 phases merged in pairs (timing only).
 // RB = 16-row blocks per wave and A-half: 4 = the full 256-row tile; 3 / 2 = TAIL tiles of 192 / 128 rows.  A tail tile keeps the
 // LDS layout and the DMA / phase schedule of the full tile, but only the first RG = 16 * RB rows of every 64-row group hold pixels
 // (LDS row r <-> tile row (r >> 6) * RG + (r & 63)); the other rows are fed by out-of-range DMAs (zeros, no traffic) and their MFMAs,
@@ -94,13 +101,13 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // records of the two descriptors: set to 0 behind the last K-step (every lane out of range: zeros land in a buffer nobody reads)
+  unsigned nrec_a = p.src_bytes - p.a_min, nrec_b = p.w_bytes;
 
   // ---- DMA bookkeeping: instruction j of this wave fills rows 8*(wave + 8j) .. +7 of a half-tile; lane -> (row, 16-byte slot)
   const int lrow = lane >> 3, slot = lane & 7;
   const int chunk = slot ^ ((4 * wave + (lane >> 4)) & 7);      // logical 16-byte chunk of the row this lane fetches
-  unsigned a_off[4], a_mask[4], b_off[4];                        // index = 2 * half + j
+  unsigned a_off[4], a_pad[4], b_off[4];                         // index = 2 * half + j
   {
     const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
@@ -121,7 +128,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
         const int sh = sh0 + p.dh0 + p.dhs * th;
         if (ok && sh >= 0 && sh < p.Hs) mk |= wb << (th * p.KW);
       }
-      a_mask[i] = mk;
+      a_pad[i] = __builtin_amdgcn_alignbit(~mk, ~mk, 1);          // "tap t is padding" bits, rotated so that tap 0's bit is bit 31
       const int n = n0 + 128 * (i >> 1) + 8 * (wave + 8 * (i & 1)) + lrow;
       b_off[i] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
     }
@@ -134,51 +141,53 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
   // The per-tap byte offsets sit in one VGPR each (lane t = tap t <= 25) and advance() picks them with v_readlane: the walk used to
   // recompute them with a dozen dependent s_mul / s_add and two branches per K-step, inside P1's load part that the partner group's
   // MFMA cluster waits for (s_memtime stamps, tools/v4_diag: P1 ran ~280 cycles longer than P3, which issues the same reads and DMA).
+  // advance() itself (two v_readlane, four mask rotations) now runs in the middle of P1's MFMA cluster.
   const int ntaps = p.KH * p.KW;
   int vtap_a, vtap_b;
   {
     const int t = lane < ntaps ? lane : 0;
     const int th = t / p.KW, tw = t - th * p.KW;
-    vtap_a = ((p.dh0 + p.dhs * th) * p.Ws + p.dw0 + p.dws * tw) * (int)p.src_ld * 2;
+    vtap_a = ((p.dh0 + p.dhs * th) * p.Ws + p.dw0 + p.dws * tw) * (int)p.src_ld * 2 - p.a_min;      // >= 0
     vtap_b = (int)((((long)((p.kh0 + p.khs * th) * p.KWf + p.kw0 + p.kws * tw)) * p.Cs) * 2);
   }
-  int sk = 0, s_tap = 0, s_ci2 = 0, s_bit = 0;
+  int sk = 0, s_tap = 0, s_ci2 = 0;
   int a_koff = __builtin_amdgcn_readlane(vtap_a, 0);
-  unsigned b_koff = (unsigned)__builtin_amdgcn_readlane(vtap_b, 0);
+  int b_koff = __builtin_amdgcn_readlane(vtap_b, 0);
   auto advance = [&]() {
     ++sk;
     const bool wrap = s_tap + 1 == ntaps;
     s_tap = wrap ? 0 : s_tap + 1;
     s_ci2 += wrap ? 2 * BK : 0;
     a_koff = __builtin_amdgcn_readlane(vtap_a, s_tap) + s_ci2;
-    b_koff = (unsigned)(__builtin_amdgcn_readlane(vtap_b, s_tap) + s_ci2);
-    s_bit = s_tap;               // bit th * KW + tw of the window masks
-    if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a buffer nobody reads again)
-      s_bit = 31;
-      b_koff = 0x80000000u;
-    }
+    b_koff = __builtin_amdgcn_readlane(vtap_b, s_tap) + s_ci2;
+    const int rot = wrap ? (33 - ntaps) & 31 : 1;                  // next tap's padding bit to bit 31
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_pad[i] = __builtin_amdgcn_alignbit(a_pad[i], a_pad[i], rot);
+    if (sk >= p.nk) { nrec_a = 0; nrec_b = 0; a_koff = 0; b_koff = 0; }
   };
-  if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
+  if (p.nk < 1) { nrec_a = 0; nrec_b = 0; a_koff = 0; b_koff = 0; }
   bool in_loop = false;
   auto stage_a = [&](int buf, int h) {
     if ((ABL & 1) && in_loop) return;
     if (ABL & 16) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + p.a_min), 0, nrec_a, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int i = 2 * h + j;
-      const unsigned v = ((a_mask[i] >> s_bit) & 1u) ? a_off[i] + (unsigned)a_koff : A_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_A1 : OFF_A0) + (wave + 8 * j) * 1024), 16,
-                                               (int)v, 0, 0, 0);
+      const unsigned v = (a_pad[i] & 0x80000000u) | a_off[i];       // padding -> beyond any extent (a_off < 2^31)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_A1 : OFF_A0) + (wave + 8 * j) * 1024), 16,
+                                               (int)v, a_koff, 0, 0);
     }
   };
   auto stage_b = [&](int buf, int h) {
     if ((ABL & 1) && in_loop) return;
     if (ABL & 32) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, nrec_b, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int i = 2 * h + j;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_B1 : OFF_B0) + (wave + 8 * j) * 1024), 16,
-                                               (int)(b_off[i] + b_koff), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BUF + (h ? OFF_B1 : OFF_B0) + (wave + 8 * j) * 1024), 16,
+                                               (int)b_off[i], b_koff, 0, 0);
     }
   };
 
@@ -220,8 +229,7 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
       bfr[rs][j][1] = rd(buf * BUF + (h ? OFF_B1 : OFF_B0) + (b_rd ^ 64) + 2048 * j);
     }
   };
-  // `mid` runs between the two k-halves of the cluster: with ABL & 1024 the phase's DMA is issued there (experiment: the DMA issue
-  // then waits on this wave's own matrix pipe instead of lengthening the load part the partner wave is waiting for)
+  // `mid` runs between the two k-halves of the cluster (P1: the K-walk bookkeeping, whose VALU then issues between this wave's own MFMAs)
   auto mma = [&](int ah, int bh, int rs, auto mid) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL & 256) __builtin_amdgcn_s_setprio(0);
@@ -253,7 +261,6 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     if (ABL & 256) __builtin_amdgcn_s_setprio(1);       // (experiment: the loading wave gets the priority)
     __builtin_amdgcn_sched_barrier(0);
   };
-  constexpr bool DMA_MID = (ABL & 1024) != 0;
   auto nothing = []() {};
 
   // ---- prologue: K-step 0 complete + three half-tiles of K-step 1 in flight
@@ -286,57 +293,49 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
     stamp(3, 2);                                   // (closes the previous phase: second barrier of P4)
     read_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA_MID) { stage_a(b ^ 1, 1); advance(); }
+    stage_a(b ^ 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     stamp(0, 0);
-    if (DMA_MID) mma(0, 0, b, [&]() { stage_a(b ^ 1, 1); advance(); });
-    else mma(0, 0, b, nothing);
+    mma(0, 0, b, [&]() { advance(); });
     stamp(0, 1);
     if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     // P2
     stamp(0, 2);
     read_b(b, 1, b ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA_MID) stage_b(b, 0);                   // B-half 0 of this buffer was read in P4 of the previous K-step: free since then
+    stage_b(b, 0);                                 // B-half 0 of this buffer was read in P4 of the previous K-step: free since then
     __builtin_amdgcn_sched_barrier(0);
     if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     stamp(1, 0);
-    if (DMA_MID) mma(0, 1, b ^ 1, [&]() { stage_b(b, 0); });
-    else mma(0, 1, b ^ 1, nothing);
+    mma(0, 1, b ^ 1, nothing);
     stamp(1, 1);
     __builtin_amdgcn_s_barrier();
     // P3
     stamp(1, 2);
     read_a(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA_MID) stage_a(b, 0);
+    stage_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     // B-half 0 of K-step k+1 (issued in P2 of K-step k-1) has landed for this wave: everything but the 10 youngest pieces
-    // (A0 / B1 / A1 of k+1, B0 / A0 of k+2; DMA_MID: 8, this phase's refill comes later).  Behind this phase's barriers all waves
-    // have been here, so P4 may read it.
-    if (DMA_MID) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    // (A0 / B1 / A1 of k+1, B0 / A0 of k+2).  Behind this phase's barriers all waves have been here, so P4 may read it.
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp(2, 0);
-    if (DMA_MID) mma(1, 1, b ^ 1, [&]() { stage_a(b, 0); });
-    else mma(1, 1, b ^ 1, nothing);
+    mma(1, 1, b ^ 1, nothing);
     stamp(2, 1);
     if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     // P4
     stamp(2, 2);
     read_b(b ^ 1, 0, b ^ 1);                       // next K-step's B-half 0 into the register set B-half 1 has just vacated
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA_MID) stage_b(b, 1);
+    stage_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
-    // everything but the three youngest half-tiles: K-step k+1 is complete (DMA_MID: this phase's refill is issued after the wait,
-    // so only TWO half-tiles are younger than K-step k+1's last one)
-    if (DMA_MID) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // everything but the three youngest half-tiles: K-step k+1 is complete
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if (!(ABL & 2048)) __builtin_amdgcn_s_barrier();
     stamp(3, 0);
-    if (DMA_MID) mma(1, 0, b, [&]() { stage_b(b, 1); });
-    else mma(1, 0, b, nothing);
+    mma(1, 0, b, nothing);
     stamp(3, 1);
     __builtin_amdgcn_s_barrier();
   };
@@ -477,7 +476,10 @@ static int v4_variant(const dy_conv_desc* d, int mode) {
   const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
   const long w_row = d->KHf > 0 ? (long)d->KHf * d->KWf * d->Cs : (long)d->KH * d->KW * d->Cs;
   const long w_bytes = (long)d->Cd * w_row * 2;
-  if (!(src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return 0;
+  // activation descriptor: extent + the most negative tap offset folded into its base (v4_launch: a_min) stays below 2^31, the bit
+  // that marks a padded lane
+  const long halo = ((long)d->KH * d->dil * d->Ws + (long)d->KW * d->dil) * d->src_ld * 2;
+  if (!(src_bytes + halo <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return 0;
   const long tiles_m = ((long)d->N * d->Hd * d->Wd + 255) / 256;
   const long t256 = (d->Cd + 255) / 256;
   // K >= 512.  (K >= 256 is 11 % faster on the 1024->256 1x1 data gradient at 80x80 -- 487 -> 434 us -- and equal on 256->256; it was
@@ -565,6 +567,11 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
     p.w_row = (long)d->KH * d->KW * d->Cs;
   }
   p.w_bytes = (unsigned)((long)d->Cd * p.w_row * 2);
+  {
+    const int dh_lo = p.dhs < 0 ? p.dh0 + p.dhs * (p.KH - 1) : p.dh0, dw_lo = p.dws < 0 ? p.dw0 + p.dws * (p.KW - 1) : p.dw0;
+    const long lo = ((long)dh_lo * p.Ws + dw_lo) * p.src_ld * 2;
+    p.a_min = lo < 0 ? (int)lo : 0;
+  }
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.add_src = mode == 1 ? (const char*)d->add_src : nullptr; p.add_src_ld = d->add_src_ld;

@@ -99,12 +99,13 @@ __global__ void filter_params_fwd_kernel(const float* __restrict__ feat, int fea
   p[7] = 0.f;
 }
 
-__global__ void filter_params_bwd_kernel(const float* __restrict__ feat, int feat_ld, const float* __restrict__ dp,
+__global__ void filter_params_bwd_kernel(const float* __restrict__ feat, int feat_ld, const double* __restrict__ dp,
                                          float* __restrict__ df, int B) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* f = feat + (long)b * feat_ld;
-  const float* g = dp + b * 8;
+  float g[8];
+  for (int i = 0; i < 8; ++i) g[i] = (float)dp[b * 8 + i];        // the f64 sums of the f32 block partials, rounded once
   float* o = df + (long)b * feat_ld;
   for (int i = 0; i < feat_ld; ++i) o[i] = 0.f;
   float t0 = tanhf(f[0]);
@@ -203,7 +204,7 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ params,
                                                              const float* __restrict__ A, const float* __restrict__ IcA,
                                                              const float* __restrict__ ds4, float* __restrict__ dx,
-                                                             float* dparams, int B, int H, int W, int accumulate) {
+                                                             double* dparams, int B, int H, int W, int accumulate) {
   __shared__ float s_part[PW_ROWS][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * PW_ROWS + wave;
@@ -267,15 +268,17 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < PW_ROWS; ++r) v += s_part[r][k];
-      float* dp = dparams + (bc0 / 3) * 8;
-      atomic_add_f32(dp + (k == 0 ? 0 : (k == 1 ? 1 + bc0 % 3 : (k == 2 ? 4 : 5))), v);
+      // f64 atomics: the sum of ~500 f32 block partials per image does not depend on their arrival order beyond 2^-52 relative
+      // (f32 atomics here made every run of a training step differ from the last one in the regressor's gradients)
+      double* dp = dparams + (bc0 / 3) * 8;
+      atomic_add_f64(dp + (k == 0 ? 0 : (k == 1 ? 1 + bc0 % 3 : (k == 2 ? 4 : 5))), (double)v);
     }
   } else if (live && lane == 0) {
-    float* dp = dparams + b * 8;
-    atomic_add_f32(dp + 0, t_om);
-    atomic_add_f32(dp + 1 + c, t_wb);
-    atomic_add_f32(dp + 4, t_gamma);
-    atomic_add_f32(dp + 5, t_alpha);
+    double* dp = dparams + b * 8;
+    atomic_add_f64(dp + 0, (double)t_om);
+    atomic_add_f64(dp + 1 + c, (double)t_wb);
+    atomic_add_f64(dp + 4, (double)t_gamma);
+    atomic_add_f64(dp + 5, (double)t_alpha);
   }
 }
 
@@ -310,7 +313,7 @@ extern "C" int dy_filter_params_fwd(const float* feat, int feat_ld, float* param
   return 0;
 }
 
-extern "C" int dy_filter_params_bwd(const float* feat, int feat_ld, const float* dparams, float* dfeat, int B, void* stream) {
+extern "C" int dy_filter_params_bwd(const float* feat, int feat_ld, const double* dparams, float* dfeat, int B, void* stream) {
   DY_CHECK(feat && dparams && dfeat && B > 0 && feat_ld >= 15, "dy_filter_params_bwd: bad args");
   filter_params_bwd_kernel<<<dy_cdiv(B, 64), 64, 0, (hipStream_t)stream>>>(feat, feat_ld, dparams, dfeat, B);
   DY_LAUNCH_CHECK();
@@ -328,7 +331,7 @@ extern "C" int dy_filters_pointwise_fwd(const float* x, const float* params, con
 }
 
 extern "C" int dy_filters_pointwise_bwd(const float* x, const float* params, const float* A, const float* IcA,
-                                        const float* ds4, float* dx, float* dparams, int B, int H, int W, int accumulate,
+                                        const float* ds4, float* dx, double* dparams, int B, int H, int W, int accumulate,
                                         int fast_math, void* stream) {
   DY_CHECK(x && params && ds4 && dparams && B > 0 && H > 0 && W >= 3, "dy_filters_pointwise_bwd: bad args");
   const unsigned grid = dy_cdiv((long)B * 3 * H, PW_ROWS);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NTH, 4) void usm_fwd_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(NTH, 3) void usm_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout8, int ld8,
                                                        const float* __restrict__ hp, const float* __restrict__ params,
-                                                       float* __restrict__ ds4, float* dparams, int B, int H, int W) {
+                                                       float* __restrict__ ds4, double* dparams, int B, int H, int W) {
   __shared__ float tileT[LW * PT];
   __shared__ float tmp[LH * PM];
   __shared__ float sm[20];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NTH, 3) void usm_bwd_kernel(const float* __restrict
     }
   }
   dl = block_sum(dl, sm);
-  if (tid == 0) atomic_add_f32(dparams + b * 8 + 6, dl);
+  if (tid == 0) atomic_add_f64(dparams + b * 8 + 6, (double)dl);      // f64: order-free sum of the block partials (see pointwise_bwd_kernel)
 }
 
 bool g_taps_ready = false;
@@ -364,7 +364,7 @@ extern "C" int dy_usm_fwd(const float* s4, const float* params, float* out_nchw,
 }
 
 extern "C" int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc8, int dout_ld, const float* hp, const float* params,
-                          float* ds4, float* dparams, int B, int H, int W, int dtype, void* stream) {
+                          float* ds4, double* dparams, int B, int H, int W, int dtype, void* stream) {
   DY_CHECK(dout_nhwc8 == nullptr || dout_ld >= 3 || dout_ld == 0, "dy_usm_bwd: bad dout_ld");
   DY_CHECK((dout_nchw != nullptr) != (dout_nhwc8 != nullptr), "dy_usm_bwd: exactly one of dout_nchw / dout_nhwc8");
   DY_CHECK(hp && params && ds4 && dparams && B > 0 && H > R && W > R, "dy_usm_bwd: bad args");

@@ -996,7 +996,7 @@ class lowlight_recovery(DyModule):
         B, _, H, W = x.shape
         dev, f32, st = x.device, torch.float32, stream()
         need_dx = bool(needs[0])
-        dparams = torch.zeros((B, 8), dtype=f32, device=dev)
+        dparams = torch.zeros((B, 8), dtype=torch.float64, device=dev)      # f64 atomics: order-free sums (frontend.hip)
         ds4 = torch.empty((B, 3, H, W), dtype=f32, device=dev)
         if dout.is_contiguous() and dout.shape[1] == 3:       # planar gradient from the direct stem dgrad kernel
             dld = 0

@@ -166,7 +166,9 @@ int dy_resize_bwd(const float* dy_nhwc, int dy_ld, int B, int H, int W, int Ho, 
 /* feat[B, feat_ld >= 15] -> params[B,8] = (omega, s_r, s_g, s_b, gamma, alpha, lambda, 0)  (filtersB.py regressors);
  * the backward writes all feat_ld columns of dfeat (zeros beyond the used slots) */
 int dy_filter_params_fwd(const float* feat, int feat_ld, float* params, int B, void* stream);
-int dy_filter_params_bwd(const float* feat, int feat_ld, const float* dparams, float* dfeat, int B, void* stream);
+/* dparams: f64 [B,8], zeroed by the caller and accumulated by dy_usm_bwd / dy_filters_pointwise_bwd with f64 atomics (a sum of f32
+ * block partials that does not depend on their arrival order: the regressor's gradients repeat from run to run) */
+int dy_filter_params_bwd(const float* feat, int feat_ld, const double* dparams, float* dfeat, int B, void* stream);
 /* DeDark -> WB -> Gamma -> Contrast pointwise chain (filtersB.py:190-303) x -> s4 ; A [B,3] or NULL (0.8);
  * IcA [B,H,W] or NULL (0.5).  fast_math = 0: libm powf / division (f32 parity mode, comparable with torch.pow to ~1 ulp);
  * fast_math = 1: v_log_f32 / v_exp_f32 / v_rcp_f32 (~2e-6 relative; the throughput mode, 10x faster backward) */
@@ -180,11 +182,11 @@ int dy_usm_fwd(const float* s4, const float* params, float* out_nchw, void* out_
  * (dout_nchw) or, in `dtype`, a padded NHWC view with pixel stride dout_ld >= 3 / a planar [B,3,H,W] tensor when
  * dout_ld == 0 (dout_nhwc); exactly one of the two pointers is non-NULL. */
 int dy_usm_bwd(const float* dout_nchw, const void* dout_nhwc, int dout_ld, const float* hp, const float* params, float* ds4,
-               float* dparams, int B, int H, int W, int dtype, void* stream);
+               double* dparams, int B, int H, int W, int dtype, void* stream);
 /* pointwise backward: recomputes the chain from x, consumes ds4, writes dx (overwrite or +=; NULL = not needed) and
  * accumulates dparams[b, 0..5] */
 int dy_filters_pointwise_bwd(const float* x, const float* params, const float* A, const float* IcA, const float* ds4,
-                             float* dx, float* dparams, int B, int H, int W, int accumulate, int fast_math, void* stream);
+                             float* dx, double* dparams, int B, int H, int W, int accumulate, int fast_math, void* stream);
 
 /* ------------------------------------------------------------------------------------------ detection loss
  * v8DetectionLoss / RcoveryDetectionLoss (U/utils/loss.py:103-193,388-416), TaskAlignedAssigner (U/utils/tal.py),

@@ -2,7 +2,7 @@
 # same-box A/B/C of conv_v4 variants built side by side (dedark_yolo_amd/lib/var*/): interleaved repetitions
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in 1 2 3; do
-  for v in varA varB ""; do
+  for v in $(cd $ROOT/dedark_yolo_amd/lib && ls -d var* 2>/dev/null) ""; do
     export LD_LIBRARY_PATH=$ROOT/dedark_yolo_amd/lib/$v
     for shape in "3x3 256->256 @40" "3x3 512->512 @40" "3x3 256->256 @80" "1x1 2048->512 @40"; do
       echo -n "rep $rep lib ${v:-current} | "

@@ -61,11 +61,6 @@ int main(int argc, char** argv) {
   run<128 | 256>("priority to the loading wave", f, flops, st, it);
   run<0>("shipped kernel (again)", f, flops, st, it);
   run<128>("no s_setprio (again)", f, flops, st, it);
-  if (Cc >= 192) {
-    run<1024>("DMA issued inside the MFMA clusters", f, flops, st, it);
-    run<0>("shipped kernel (again)", f, flops, st, it);
-    run<1024>("DMA inside the MFMA clusters (again)", f, flops, st, it);
-  }
   run<1 | 4>("MFMA + barriers only", f, flops, st, it);
   run<1 | 4 | 2048>("MFMA + HALF the barriers (phases merged in pairs; timing only)", f, flops, st, it);
   run<2048>("everything, phases merged in pairs (WRONG results; timing only)", f, flops, st, it);
