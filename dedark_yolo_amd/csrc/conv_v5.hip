@@ -24,7 +24,7 @@ namespace v5 {
 
 constexpr int BM = 256, BK = 32;
 constexpr int A_BYTES = BM * 64, NSTAGE = 3;
-constexpr unsigned A_OOB = 0x80000000u;             // > any source extent (checked by the dispatcher: <= 2 GiB)
+// bit 31 of an activation offset marks a padded lane: beyond any source extent (checked by the dispatcher: < 2 GiB)
 constexpr unsigned B_ROW_OOB = 0x40000000u;         // weight extent <= 1 GiB: row-invalid + any k offset stays out of range
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -58,6 +58,8 @@ struct P {
   double* stats;
   int accumulate;
   long M;
+  int a_min;                     // most negative window-tap byte offset (<= 0): folded into the activation descriptor's base so that
+                                 // the per-K-step SGPR offsets of conv_kernel are >= 0 (see conv_v4.hip)
   int nk;                        // K-steps = KH*KW*Cs/32
   int tiles_n, nblk;
   const char* add_src;           // optional addend view of a data gradient (dy_conv_desc.add_src)
@@ -188,13 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // records of the two descriptors: 0 behind the last K-step (every lane out of range: zeros land in a stage nobody reads again)
+  unsigned nrec_a = p.nk > 0 ? p.src_bytes - p.a_min : 0, nrec_b = p.nk > 0 ? p.w_bytes : 0;
 
-  // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills rows 16*idx .. +15 of the A (j < 4) / B (j < 2) tile
+  // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills rows 16*idx .. +15 of the A (j < 4) / B (j < 2) tile.  As in conv_v4.hip:
+  // a lane's pixel offset is the instruction's VGPR offset for the whole K loop, tap and channel chunk travel in its SGPR offset, the
+  // padding bits of the lane's row are rotated once per K-step so that the current tap's bit is bit 31 (= out of range when set)
   const int lrow = lane >> 2, slot = lane & 3;
   const int chunk = slot ^ ((lane & 32) ? 3 : 0);          // logical 16-byte chunk (8 channels of the 32-deep step) this lane fetches
-  unsigned a_off[4], a_mask[4], b_off[B_LD];
+  unsigned a_off[4], a_pad[4], b_off[B_LD];
   {
     const DyTileWalk walk(m0, p.Hd, p.Wd);
 #pragma unroll
@@ -214,50 +218,55 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
         const int sh = sh0 + p.dh0 + p.dhs * th;
         if (ok && sh >= 0 && sh < p.Hs) mk |= wb << (th * p.KW);
       }
-      a_mask[j] = mk;
+      if (DY_ABLATE_OF(p) & 2) mk = 0;
+      else if (DY_ABLATE_OF(p) & 1) mk &= 1u;
+      a_pad[j] = __builtin_amdgcn_alignbit(~mk, ~mk, 1);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const int n = n0 + 16 * (wave + 4 * j) + lrow;
-      b_off[j] = n < p.Cd ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
+      b_off[j] = (n < p.Cd && !(DY_ABLATE_OF(p) & 4)) ? (unsigned)((long)n * p.w_row * 2 + chunk * 16) : B_ROW_OOB;
     }
   }
-  // K-step being issued (wave-uniform)
-  int sk = 0, s_th = 0, s_tw = 0, s_ci = 0, s_bit = 0;
-  int a_koff = (p.dh0 * p.Ws + p.dw0) * (int)p.src_ld * 2;
-  unsigned b_koff = (unsigned)(((long)(p.kh0 * p.KWf + p.kw0)) * p.Cs * 2);
-  if (p.nk < 1) { s_bit = 31; b_koff = 0x80000000u; }
+  // K-step being issued (wave-uniform).  K order: all taps of one BK-channel chunk, then the next chunk.  The taps re-read the SAME
+  // pixels (shifted windows), so with the taps innermost a tile's live set is (tile + halo) x BK channels (~40 KB; 32 CUs x 40 KB sit
+  // in an XCD's 4 MiB L2) and the 2nd .. 9th reads are L2 hits; tap-major order cycled through the tile's full channel depth between
+  // two reads of a line (150 KB per CU: more than its L2 share -> every tap went back to the Infinity Cache, 2.4x fabric traffic).
+  const int ntaps = p.KH * p.KW;
+  int vtap_a, vtap_b;                                      // lane t = byte offsets of tap t
+  {
+    const int t = lane < ntaps ? lane : 0;
+    const int th = t / p.KW, tw = t - th * p.KW;
+    vtap_a = ((p.dh0 + p.dhs * th) * p.Ws + p.dw0 + p.dws * tw) * (int)p.src_ld * 2 - p.a_min;      // >= 0
+    vtap_b = (int)((((long)((p.kh0 + p.khs * th) * p.KWf + p.kw0 + p.kws * tw)) * p.Cs) * 2);
+  }
+  int sk = 0, s_tap = 0, s_ci2 = 0;
+  int a_koff = __builtin_amdgcn_readlane(vtap_a, 0), b_koff = __builtin_amdgcn_readlane(vtap_b, 0);
   auto advance = [&]() {
     ++sk;
-    // K order: all taps of one BK-channel chunk, then the next chunk.  The taps re-read the SAME pixels (shifted windows), so with
-    // the taps innermost a tile's live set is (tile + halo) x BK channels (~40 KB; 32 CUs x 40 KB sit in an XCD's 4 MiB L2) and
-    // the 2nd .. 9th reads are L2 hits; tap-major order cycled through the tile's full channel depth between two reads of a
-    // line (150 KB per CU: more than its L2 share -> every tap went back to the Infinity Cache, 2.4x fabric traffic).
-    ++s_bit;
-    if (++s_tw == p.KW) {
-      s_tw = 0;
-      if (++s_th == p.KH) { s_th = 0; s_bit = 0; s_ci += BK; }
-    }
-    a_koff = ((p.dh0 + p.dhs * s_th) * p.Ws + p.dw0 + p.dws * s_tw) * (int)p.src_ld * 2 + s_ci * 2;
-    b_koff = (unsigned)((((long)((p.kh0 + p.khs * s_th) * p.KWf + p.kw0 + p.kws * s_tw)) * p.Cs + s_ci) * 2);
-    if (sk >= p.nk) {          // beyond the last K-step: every lane out of range (zeros land in a stage nobody reads again)
-      s_bit = 31;
-      b_koff = 0x80000000u;
-    }
+    const bool wrap = s_tap + 1 == ntaps;
+    s_tap = wrap ? 0 : s_tap + 1;
+    s_ci2 += wrap ? 2 * BK : 0;
+    a_koff = __builtin_amdgcn_readlane(vtap_a, s_tap) + s_ci2;
+    b_koff = __builtin_amdgcn_readlane(vtap_b, s_tap) + s_ci2;
+    const int rot = wrap ? (33 - ntaps) & 31 : 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_pad[j] = __builtin_amdgcn_alignbit(a_pad[j], a_pad[j], rot);
+    if (sk >= p.nk) { nrec_a = 0; nrec_b = 0; a_koff = 0; b_koff = 0; }
   };
   auto issue = [&](int base) {                 // one stage: 4 + 2 DMA instructions per wave, ONE unconditional load per lane each
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + p.a_min), 0, nrec_a, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, nrec_b, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      unsigned v = ((a_mask[j] >> s_bit) & 1u) ? a_off[j] + (unsigned)a_koff : A_OOB;
-      if (((DY_ABLATE_OF(p) & 1) && (s_th | s_tw)) || (DY_ABLATE_OF(p) & 2)) v = A_OOB;
-      if ((DY_ABLATE_OF(p) & 64) && (s_th | s_tw)) continue;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)v, 0, 0, 0);
+      if ((DY_ABLATE_OF(p) & 64) && s_tap) continue;
+      const unsigned v = (a_pad[j] & 0x80000000u) | a_off[j];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)v, a_koff, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + A_BYTES + (wave + 4 * j) * 1024), 16,
-                                               (int)((DY_ABLATE_OF(p) & 4) ? B_ROW_OOB : b_off[j] + b_koff), 0, 0, 0);
-    advance();
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + A_BYTES + (wave + 4 * j) * 1024), 16, (int)b_off[j], b_koff, 0,
+                                               0);
   };
 
   // ---- fragment read addresses (16x16x32 operand: lane = row l&15, chunk l>>4)
@@ -272,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int base) {               // one staged K-step: 4 + MB fragment reads, MB x 4 MFMAs
+  // one staged K-step: 4 + MB fragment reads, MB x 4 MFMAs; `mid` (the K-walk bookkeeping of the NEXT issue) runs inside the cluster
+  auto compute = [&](int base, auto mid) {
     u32x4 bfr[NB], afr[MB];
     if (DY_ABLATE_OF(p) & 16) {
 #pragma unroll
@@ -288,21 +298,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
     if (DY_ABLATE_OF(p) & 8) {
 #pragma unroll
       for (int i = 0; i < MB; ++i) acc[i][0][0] += __builtin_bit_cast(float, afr[i][0] ^ bfr[i & 3][1]);
+      mid();
       return;
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int i = 0; i < MB; ++i) {
 #pragma unroll
       for (int j = 0; j < NB; ++j)
         // transposed product (rows = output channels, columns = pixels): a lane ends up with 4 consecutive CHANNELS of one pixel
         acc[i][j] = mfma_16x16x32<T>(bfr[j], afr[i], acc[i][j]);
+      if (i == 0) mid();
+    }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto nothing = []() {};
+  auto walk = [&]() { advance(); };
   stamp(DY_ABLATE_OF(p), p.nblk, 1);
   if constexpr (BN >= 128) {
     issue(0);
+    advance();
     issue(STAGE);
+    advance();
     int cur = 0, fill = 2 * STAGE;
     for (int kt = 0; kt < p.nk; ++kt) {
       if (DY_ABLATE_OF(p) & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
       __builtin_amdgcn_sched_barrier(0);
       issue(fill);                                         // K-step kt + 2 into the stage K-step kt - 1 occupied
       __builtin_amdgcn_sched_barrier(0);
-      compute(cur);
+      compute(cur, walk);
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == 2 * STAGE ? 0 : cur + STAGE;
       fill = fill == 2 * STAGE ? 0 : fill + STAGE;
@@ -322,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
     // steps go in PAIRS: four stages, one wait + barrier per two K-steps (32 MFMAs), the next pair in flight meanwhile.  An odd
     // last step computes on a zero-filled stage.
     issue(0);
+    advance();
     issue(STAGE);
+    advance();
     int cur = 0;
     for (int kt = 0; kt < p.nk; kt += 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this pair has landed (nothing younger is in flight)
@@ -330,10 +349,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
       __builtin_amdgcn_sched_barrier(0);
       const int nxt = cur ^ (2 * STAGE);
       issue(nxt);                                          // next pair into the two stages the previous pair occupied
+      advance();
       issue(nxt + STAGE);
       __builtin_amdgcn_sched_barrier(0);
-      compute(cur);
-      compute(cur + STAGE);
+      compute(cur, walk);
+      compute(cur + STAGE, nothing);
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
@@ -379,8 +399,6 @@ __global__ __launch_bounds__(256, 2) void band_kernel(const P p) {
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   if (tid < 16) reinterpret_cast<unsigned*>(smem + OFF_ZERO)[tid] = 0u;      // the zero row (visible after the first barrier)
 
   // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills band rows 16*idx .. +15 (j < 4) / weight rows (j < B_LD); the 17th
@@ -401,24 +419,29 @@ __global__ __launch_bounds__(256, 2) void band_kernel(const P p) {
   }
   const int ng = p.nk / 3;                     // bands: (32-channel chunk, kernel row)
   int ga_n = 0, ga_th = 0, ga_ci = 0;          // band being issued (wave-uniform)
+  // (a dead band / weight tile -- beyond the last one -- uses a descriptor of zero records: every lane out of range, zeros land; the
+  // band's kernel-row offset is added per lane: a band may start one pixel in front of the tensor and end up to a row behind it, and only
+  // the full 32-bit sum is range-checked by the hardware; the weight tile's offset travels in the instruction's SGPR offset)
   auto issue_band = [&](int base) {
     const bool live = ga_n < ng && !(DY_ABLATE_OF(p) & 2);
     const unsigned koff = (unsigned)((p.dh0 + p.dhs * ga_th) * p.Ws * (int)p.src_ld * 2 + ga_ci * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, live ? p.src_bytes : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16,
-                                               (int)(live ? a_off[j] + koff : A_OOB), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)(a_off[j] + koff), 0, 0, 0);
     if (tail_lane)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + base + 16 * 1024), 16, (int)(live ? a_off[4] + koff : A_OOB), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + base + 16 * 1024), 16, (int)(a_off[4] + koff), 0, 0, 0);
     ++ga_n;
     if (++ga_th == 3) { ga_th = 0; ga_ci += BK; }
   };
   int kb = 0, kb_tp = 0, kb_ci = 0;            // weight tile being issued: K order = chunk, kernel row, kernel column
   auto issue_b = [&](int base) {
-    const unsigned koff = (kb < p.nk && !(DY_ABLATE_OF(p) & 4)) ? (unsigned)(((long)kb_tp * p.Cs + kb_ci) * 2) : 0x80000000u;
+    const bool live = kb < p.nk && !(DY_ABLATE_OF(p) & 4);
+    const int koff = live ? (int)(((long)kb_tp * p.Cs + kb_ci) * 2) : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? p.w_bytes : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)(b_off[j] + koff), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + base + (wave + 4 * j) * 1024), 16, (int)b_off[j], koff, 0, 0);
     ++kb;
     if (++kb_tp == 9) { kb_tp = 0; kb_ci += BK; }
   };
@@ -572,7 +595,9 @@ bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
   const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
   const long w_row = d->KHf > 0 ? (long)d->KHf * d->KWf * d->Cs : (long)d->KH * d->KW * d->Cs;
   const long w_bytes = (long)d->Cd * w_row * 2;
-  if (!(src_bytes <= 0x7fffffffL && w_bytes <= 0x3fffffffL && M < (1L << 31))) return false;
+  // (activation extent + the most negative tap offset folded into the descriptor's base stay below 2^31, the bit of a padded lane)
+  const long halo = ((long)d->KH * d->dil * d->Ws + (long)d->KW * d->dil) * d->src_ld * 2;
+  if (!(src_bytes + halo <= 0x7fffffffL && w_bytes <= 0x3fffffffL && M < (1L << 31))) return false;
   const long tiles_m = (M + 255) / 256;
   const long tn = (d->Cd + 127) / 128;
   if (d->Cd >= 96 && tn * 128 * 4 <= (long)d->Cd * 5 && tiles_m * tn >= 256) return true;
@@ -599,6 +624,11 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     p.w_row = (long)d->KH * d->KW * d->Cs;
   }
   p.w_bytes = (unsigned)((long)d->Cd * p.w_row * 2);
+  {
+    const int dh_lo = p.dhs < 0 ? p.dh0 + p.dhs * (p.KH - 1) : p.dh0, dw_lo = p.dws < 0 ? p.dw0 + p.dws * (p.KW - 1) : p.dw0;
+    const long lo = ((long)dh_lo * p.Ws + dw_lo) * p.src_ld * 2;
+    p.a_min = lo < 0 ? (int)lo : 0;
+  }
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.add_src = mode == 1 ? (const char*)d->add_src : nullptr; p.add_src_ld = d->add_src_ld;

@@ -10,9 +10,12 @@
 // 256-byte rows (16-byte chunk c of row r at slot c ^ (((r&3)<<2) | ((r>>2)&3))) and the fragments are read with
 // ds_read_b64_tr_b16 (the CDNA4 transposing LDS read: 4 pixels x 16 channels -> each lane the 4 pixels of ITS channel), conflict-free
 // for the 16x16x32 operand (the two 16-lane groups of a half read blocks 8 pixels apart).
-//   * every lane's 16-byte chunk belongs to ONE (tap, channel) for the whole kernel; per K-step a lane only advances the (image,
-//     row, column) of its two pixel rows (mixed-radix add of 64 pixels, no divisions) and tests the tap against the image border;
-//     padding taps and everything beyond M use an offset outside the buffer descriptor (the hardware writes zeros);
+//   * every lane's 16-byte chunk belongs to ONE (tap, channel) for the whole kernel; per K-step a lane only advances the (row, column)
+//     of its two pixel rows (mixed-radix add of 64 pixels, no divisions; the byte offset moves by three wave-uniform deltas selected by
+//     the carries) and tests the tap against the image border; padding taps and everything beyond M use an offset outside the buffer
+//     descriptor (the hardware writes zeros).  ALL of that arithmetic runs in the middle of the wave's own MFMA clusters and leaves four
+//     ready DMA offsets in registers: the load part of a phase -- the part the partner wave group's cluster waits for -- issues its
+//     LDS-DMA pieces without a single VALU instruction (the dz pieces carry the K-step in their descriptor's base address);
 //   * the pixel range is split over blocks (one round of blocks over the chip); consecutive logical blocks = the k' x co tiles of ONE
 //     pixel range and the XCD-aware block order keeps them on one XCD: dz and x of that range are fetched from HBM once and shared
 //     through that XCD's L2 by its tiles;
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
   const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
   const int nk = m_begin < m_end ? (int)((m_end - m_begin + BKP - 1) / BKP) : 0;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
+  // records of the two descriptors: 0 behind the block's last K-step (every lane out of range: zeros land in a unit nobody reads)
+  unsigned nrec_a = nk > 0 ? p.x_bytes : 0, nrec_b = nk > 0 ? p.dz_bytes : 0;
 
   // ---- DMA bookkeeping: wave instruction idx = wave + 8j (j = 0, 1) fills rows 4*idx .. 4*idx+3 of a unit; lane -> (row, slot)
   const int lrow = lane >> 4, slot = lane & 15;
@@ -88,35 +91,37 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
   // x side: this lane's chunk of unit u is channel block (tap, ci) of k' = kp0 + 128u + 8*chunk
   int a_dh[2], a_dw[2];
   unsigned a_tap[2];             // byte offset of (tap, ci) relative to the output pixel's source position
-  bool a_kok[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = kp0 + 128 * u + 8 * chunk;
-    a_kok[u] = k < p.Ktot;
-    const int kk = a_kok[u] ? k : 0;
+    const bool kok = k < p.Ktot;
+    const int kk = kok ? k : 0;
     const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     a_dh[u] = kh * p.dil - p.pad;
     a_dw[u] = kw * p.dil - p.pad;
     a_tap[u] = (unsigned)(((long)a_dh[u] * p.Wi + a_dw[u]) * p.x_ld * 2 + ci * 2);
+    if (!kok) a_dh[u] = 0x40000000;           // k' beyond K: the row test below fails for every pixel
   }
-  // pixel rows of this lane: m_begin + 4*(wave + 8j) + lrow (+ 64 per K-step)
-  int pn[2], ph[2], pw[2];
+  // pixel rows of this lane: m_begin + 4*(wave + 8j) + lrow (+ 64 per K-step); kept as SOURCE coordinates (output row / column times
+  // the stride) so that the border test needs no multiplication
+  int ph[2], pw[2];
   unsigned a_pix[2];             // byte offset of the source position of the row's output pixel at tap (0,0) without padding shift
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const long m = m_begin + 4 * (wave + 8 * j) + lrow;
     if (POINTWISE) {
       a_pix[j] = (unsigned)(m * p.x_ld * 2);
-      pn[j] = ph[j] = pw[j] = 0;
+      ph[j] = pw[j] = 0;
     } else {
       const unsigned mu = (unsigned)m;
       const unsigned HWo = (unsigned)(p.Ho * p.Wo);
-      pn[j] = (int)(mu / HWo);
-      const unsigned rem = mu - (unsigned)pn[j] * HWo;
-      ph[j] = (int)(rem / (unsigned)p.Wo);
-      pw[j] = (int)(rem - (unsigned)ph[j] * (unsigned)p.Wo);
-      a_pix[j] = 0;
+      const int pn = (int)(mu / HWo);
+      const unsigned rem = mu - (unsigned)pn * HWo;
+      const int oh = (int)(rem / (unsigned)p.Wo), ow = (int)(rem - (unsigned)oh * (unsigned)p.Wo);
+      ph[j] = oh * p.stride;
+      pw[j] = ow * p.stride;
+      a_pix[j] = (unsigned)((((long)pn * p.Hi + ph[j]) * p.Wi + pw[j]) * p.x_ld * 2);
     }
   }
   // dz side: row m, channels q0 + 128u + 8*chunk
@@ -128,61 +133,73 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
     for (int j = 0; j < 2; ++j)
       b_off[u][j] = co < p.Cout ? (unsigned)((long)(4 * (wave + 8 * j) + lrow) * p.dz_ld * 2 + co * 2) : B_COL_OOB;
   }
-  unsigned b_koff = (unsigned)(m_begin * p.dz_ld * 2);      // K-step being issued (wave-uniform)
+  // K-step being issued (wave-uniform): the dz descriptor's BASE moves with it and its records shrink by as much, so that the rows
+  // beyond M of the last K-step are out of range by their VGPR offset alone (an SGPR offset is not part of the hardware's range check)
+  int b_koff = nk > 0 ? (int)(m_begin * p.dz_ld * 2) : 0;
+  if (nk > 0) nrec_b -= (unsigned)b_koff;
   int sk = 0;
-  bool alive = nk > 0;
-  if (!alive) b_koff = 0x80000000u;
-
-  auto pix_offsets = [&]() {                                 // source byte offset of each row's output pixel
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      a_pix[j] = (unsigned)((((long)pn[j] * p.Hi + ph[j] * p.stride) * p.Wi + pw[j] * p.stride) * p.x_ld * 2);
-  };
-  if (!POINTWISE) pix_offsets();
   auto advance_scalar = [&]() {
     ++sk;
-    b_koff += (unsigned)(BKP * p.dz_ld * 2);
-    if (sk >= nk) {
-      alive = false;
-      b_koff = 0x80000000u;
-    }
+    b_koff += (int)(BKP * p.dz_ld * 2);
+    const unsigned step = (unsigned)(BKP * p.dz_ld * 2);
+    nrec_b = nrec_b > step ? nrec_b - step : 0;
+    if (sk >= nk) { nrec_a = 0; nrec_b = 0; b_koff = 0; }
   };
-  auto advance_rows = [&]() {                                // + 64 pixels: mixed-radix add on (image, row, column)
+  // + 64 pixels: mixed-radix add on (row, column) with the carries selecting the byte delta.  offset(n, h, w) = ((n*Hi + h*s)*Wi + w*s)*ld:
+  // per output column e_w = s*ld, per output row e_h = s*Wi*ld, per image e_n = Hi*Wi*ld
+  const int e_w = p.stride * (int)p.x_ld * 2, e_h = p.stride * p.Wi * (int)p.x_ld * 2, e_n = p.Hi * p.Wi * (int)p.x_ld * 2;
+  const int d_base = p.q_h * e_n + p.r_h * e_h + p.r64_w * e_w, d_cw = e_h - p.Wo * e_w, d_ch = e_n - p.Ho * e_h;
+  const int s_rw = p.r64_w * p.stride, s_rh = p.r_h * p.stride, s_Wo = p.Wo * p.stride, s_Ho = p.Ho * p.stride;
+  auto advance_rows = [&]() {
     if (POINTWISE) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) a_pix[j] += (unsigned)(BKP * p.x_ld * 2);
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int w = pw[j] + p.r64_w, h = ph[j] + p.r_h, n = pn[j] + p.q_h;
-      if (w >= p.Wo) { w -= p.Wo; ++h; }
-      if (h >= p.Ho) { h -= p.Ho; ++n; }
-      if (h >= p.Ho) { h -= p.Ho; ++n; }                     // r_h + carry can pass Ho once more only when r_h == Ho - 1 and carry
-      pw[j] = w; ph[j] = h; pn[j] = n;
+    for (int j = 0; j < 2; ++j) {                            // (selects, no branches: this sits between MFMAs)
+      int w = pw[j] + s_rw, h = ph[j] + s_rh;
+      const bool cw = w >= s_Wo;
+      w -= cw ? s_Wo : 0;
+      h += cw ? p.stride : 0;
+      int d = d_base + (cw ? d_cw : 0);
+      const bool c1 = h >= s_Ho;
+      h -= c1 ? s_Ho : 0;
+      d += c1 ? d_ch : 0;
+      const bool c2 = h >= s_Ho;                             // r_h + carry can pass Ho once more only when r_h == Ho - 1 and carry
+      h -= c2 ? s_Ho : 0;
+      d += c2 ? d_ch : 0;
+      pw[j] = w; ph[j] = h;
+      a_pix[j] += (unsigned)d;
     }
-    pix_offsets();
+  };
+  // the ready DMA offsets of unit u for the lane's two rows: ONE unconditional DMA per lane with a selected offset (an exec-masked DMA
+  // would leave stale bytes in LDS instead of zeros)
+  unsigned a_v[2][2];            // [u][j]
+  auto offsets_of = [&](int u) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool ok = a_dh[u] < 0x40000000;
+      if (!POINTWISE) {
+        const int ih = ph[j] + a_dh[u], iw = pw[j] + a_dw[u];
+        ok = ((unsigned)ih < (unsigned)p.Hi) & ((unsigned)iw < (unsigned)p.Wi);
+      }
+      a_v[u][j] = ok ? a_pix[j] + a_tap[u] : A_OOB;
+    }
   };
   auto stage_a = [&](int buf, int u) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      // ONE unconditional DMA per lane with a selected offset (an exec-masked DMA would leave stale bytes in LDS instead of zeros)
-      int okm = (a_kok[u] ? -1 : 0) & (alive ? -1 : 0);
-      if (!POINTWISE) {
-        const int ih = ph[j] * p.stride + a_dh[u], iw = pw[j] * p.stride + a_dw[u];
-        okm &= ((unsigned)ih < (unsigned)p.Hi ? -1 : 0) & ((unsigned)iw < (unsigned)p.Wi ? -1 : 0);
-      }
-      unsigned v = ((a_pix[j] + a_tap[u]) & (unsigned)okm) | (A_OOB & ~(unsigned)okm);
-      asm volatile("" : "+v"(v));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + buf * BUF + (u ? OFF_A1 : OFF_A0) + (wave + 8 * j) * 1024), 16,
-                                               (int)v, 0, 0, 0);
-    }
-  };
-  auto stage_b = [&](int buf, int u) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, nrec_a, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + buf * BUF + (u ? OFF_B1 : OFF_B0) + (wave + 8 * j) * 1024), 16,
-                                               (int)(b_off[u][j] + b_koff), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BUF + (u ? OFF_A1 : OFF_A0) + (wave + 8 * j) * 1024), 16,
+                                               (int)a_v[u][j], 0, 0, 0);
+  };
+  auto stage_b = [&](int buf, int u) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dz + b_koff), 0, nrec_b, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BUF + (u ? OFF_B1 : OFF_B0) + (wave + 8 * j) * 1024), 16,
+                                               (int)b_off[u][j], 0, 0, 0);
   };
 
   // ---- transposed-read addresses.  16-lane group gg = lane>>4 reads pixels 8*gg + 4*t + (0..3) (t = 0, 1) of a 32-pixel block;
@@ -245,33 +262,66 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
     WG4_FRAG(bfr[U][1][0], b_vad[0][1], b_vad[1][1], (BASE));                          \
     WG4_FRAG(bfr[U][1][1], b_vad[0][1], b_vad[1][1], (BASE) + 8192);                   \
   } while (0)
-  auto mma = [&](int ah, int bh) {
+  // `mid` runs between the two k-halves of the cluster: the K-walk arithmetic of the phases to come, whose VALU instructions then issue
+  // in the gaps of this wave's own MFMAs instead of in a load part (`live` = the tile half exists; the bookkeeping runs either way)
+  // LIVE = the tile half exists (the bookkeeping runs either way); GAP = VALU instructions of `mid` the scheduler places behind each MFMA
+  auto mma = [&](int ah, int bh, auto livec, auto gapc, auto mid) {
+    constexpr bool LIVE = decltype(livec)::value;
+    constexpr int GAP = decltype(gapc)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (LIVE) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[ah][bh][i][j] = mfma_16x16x32<T>(afr[i][kb], bfr[bh][j][kb], acc[ah][bh][i][j]);
+          for (int j = 0; j < 2; ++j)
+            acc[ah][bh][i][j] = mfma_16x16x32<T>(afr[i][kb], bfr[bh][j][kb], acc[ah][bh][i][j]);
+        if (kb == 0) mid();
+      }
+      if constexpr (GAP > 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+          __builtin_amdgcn_sched_group_barrier(0x002, GAP, 0);    // ... then GAP VALU of the bookkeeping in its shadow
+        }
+      }
+    } else {
+      mid();
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
+  // pins the K-walk state behind the point where it is called: without it the compiler starts the arithmetic of a `mid` block early,
+  // in the load part in front of the cluster's barrier
+  auto pin_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pw[j]), "+v"(ph[j]), "+v"(a_pix[j]));
+  };
+  auto pin_offsets = [&](int u) {                            // ... and its results in front of the point where they are first used
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(a_v[u][j]));
+  };
 
   // ---- prologue: K-step 0 complete + three units of K-step 1 in flight
+  offsets_of(0); offsets_of(1);
   stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
   advance_scalar();
   advance_rows();
+  offsets_of(0); offsets_of(1);                         // rows of K-step 1: unit 0 goes out here, unit 1 in P1 of the first K-step
   stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
 
   // One K-step on buffer `cur` (0 / 1).  The read addresses carry the buffer base (the ds offset field is 16 bits) and are
-  // flipped after every K-step; DMA destinations are scalar.
+  // flipped in the last cluster of every K-step; DMA destinations are scalar.
   int cur = 0;
+  using yes = std::true_type;
+  auto kloop = [&](auto a1c, auto b1c) {
+  constexpr bool A1 = decltype(a1c)::value, B1 = decltype(b1c)::value;
   for (int kt = 0; kt < nk; ++kt) {
     const int b = cur, bo = cur ^ 1;
     // P1: B unit 0 (8 transposing reads, retired before the barrier), A unit 0 (16); refill A unit 1 of the next K-step
@@ -280,26 +330,26 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
     WG4_READ_A2(OFF_A0, 0);
     __builtin_amdgcn_sched_barrier(0);
     stage_a(bo, 1);
-    advance_scalar();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     WG4_READ_A2(OFF_A0, 2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(0, 0);
+    mma(0, 0, yes{}, std::integral_constant<int, 0>{}, [&]() { advance_scalar(); });
     __builtin_amdgcn_s_barrier();
-    // P2: B unit 1; refill B unit 0 two K-steps ahead; the rows move on by 64 pixels
-    if (has_b1) WG4_READ_B(OFF_B1, 1);
+    // P2: B unit 1; refill B unit 0 two K-steps ahead; in the cluster the rows move on by 64 pixels (K-step kt + 2) and unit 0's
+    // offsets for P3 are made
+    if (B1) WG4_READ_B(OFF_B1, 1);
     __builtin_amdgcn_sched_barrier(0);
     stage_b(b, 0);
-    advance_rows();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (has_b1) mma(0, 1);
+    mma(0, 1, std::bool_constant<B1>{}, std::integral_constant<int, POINTWISE ? 1 : 3>{},
+        [&]() { pin_rows(); advance_rows(); offsets_of(0); pin_rows(); pin_offsets(0); });
     __builtin_amdgcn_s_barrier();
-    // P3: A unit 1; refill A unit 0
-    if (has_a1) {
+    // P3: A unit 1; refill A unit 0; in the cluster unit 1's offsets for P1 of the next K-step
+    if (A1) {
       WG4_READ_A2(OFF_A1, 0);
       WG4_READ_A2(OFF_A1, 2);
     }
@@ -307,24 +357,37 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const P p) {
     stage_a(b, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (has_b1 && has_a1) mma(1, 1);
+    mma(1, 1, std::bool_constant<A1 && B1>{}, std::integral_constant<int, 1>{}, [&]() { pin_rows(); offsets_of(1); pin_offsets(1); });
     __builtin_amdgcn_s_barrier();
-    // P4: refill B unit 1; everything but the three youngest units has landed
+    // P4: refill B unit 1; everything but the three youngest units has landed; in the cluster the read addresses flip to the other buffer
     stage_b(b, 1);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (has_a1) mma(1, 0);
-    __builtin_amdgcn_s_barrier();
-    const int delta = cur ? -BUF : BUF;
+    {
+      const int delta = cur ? -BUF : BUF;
+      auto mid = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a_vad[t][i] += delta;
+          for (int i = 0; i < 4; ++i) { a_vad[t][i] += delta; asm volatile("" : "+v"(a_vad[t][i])); }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b_vad[t][j] += delta;
+          for (int j = 0; j < 2; ++j) { b_vad[t][j] += delta; asm volatile("" : "+v"(b_vad[t][j])); }
+        }
+      };
+      mma(1, 0, std::bool_constant<A1>{}, std::integral_constant<int, 1>{}, mid);
     }
+    __builtin_amdgcn_s_barrier();
     cur ^= 1;
+  }
+  };
+  // (block-uniform: one specialisation of the loop per combination of existing tile halves, so that a cluster is one basic block)
+  if (has_a1) {
+    if (has_b1) kloop(std::true_type{}, std::true_type{});
+    else kloop(std::true_type{}, std::false_type{});
+  } else {
+    if (has_b1) kloop(std::false_type{}, std::true_type{});
+    else kloop(std::false_type{}, std::false_type{});
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
