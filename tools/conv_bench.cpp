@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         dy_debug_conv5_stamps(t);
         for (int b = 0; b < 16; b += 8)
-          printf("   %s %s block (10 ns ticks): start +%llu | prologue %llu | K loop %llu | lds image %llu | stores %llu | stats %llu | total %llu\n", which ? "dgrad" : "fwd",
+          printf("   %s %s block (shader clocks): start +%llu | prologue %llu | K loop %llu | lds image %llu | stores %llu | stats %llu | total %llu\n", which ? "dgrad" : "fwd",
                  b ? "late" : "first", t[b] - t[0], t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], t[b + 5] - t[b + 4], t[b + 5] - t[b]);
       }
     } else if (getenv("DY_ABLATE") && (atoi(getenv("DY_ABLATE")) & 32)) {
