@@ -510,6 +510,37 @@ def test_n_max_of_never_inherits_another_batch():
     assert n_max_of(b, 3) == 6
 
 
+def test_freezing_parameters_between_steps_is_noticed():
+    """The graph's autograd node is fed the trainable parameters; their requires_grad flags are read every step (from a cached tuple of
+    the Parameter objects), so freezing / unfreezing a layer after model.train() takes effect at the next backward."""
+    import dedark_yolo_amd as dy
+    from parity_helpers import build_models, make_batch
+    dy.set_compute_dtype(torch.float32)
+    model, _ = build_models("yolov8-lowlight.yaml", "t", (0.33, 0.125, 1024), 21)
+    batch = make_batch(22, 2, 64, [2, 3])
+    gb = dict(batch)
+    gb["img"] = batch["img"].pow(3.0).cuda()
+    gb["recovery_loss_batch"] = torch.tensor(0.01, device="cuda")
+    model.train()
+    w = model.model[1].conv.weight                     # the stem conv behind the front-end
+    other = model.model[2].conv.weight
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        loss, _ = model(dict(gb))
+        loss.backward()
+        torch.cuda.synchronize()
+        return (None if w.grad is None else w.grad.clone()), other.grad.clone()
+    g0, o0 = grads()
+    assert g0 is not None and float(g0.abs().sum()) > 0
+    w.requires_grad_(False)
+    g1, o1 = grads()
+    assert g1 is None and torch.allclose(o1, o0, rtol=1e-4, atol=1e-7)
+    w.requires_grad_(True)
+    g2, _ = grads()
+    assert g2 is not None and torch.allclose(g2, g0, rtol=1e-4, atol=1e-7)
+
+
 def test_deterministic_flag_selects_the_one_stream_schedule():
     """args.deterministic (reference cfg/default.yaml:23, default True): the one-stream schedule.  Every cross-block sum of the step is
     either added in a fixed order (weight-gradient slabs, LDS partials) or an f64 atomic sum of f32 partials (BatchNorm / loss / clip /

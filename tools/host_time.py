@@ -77,6 +77,11 @@ def main():
     # forward / backward split of the host time
     import cProfile
     import pstats
+    # the autograd engine runs a CUDA graph's backward on its own thread, which cProfile does not see: keep it on this one
+    torch.autograd.set_multithreading_enabled(False)
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
     for i in range(5):
