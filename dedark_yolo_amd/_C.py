@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdedark_yolo.so")
+# DY_LIB_DIR (diagnostics: same-box A/B of two builds of the library, tools/gpu/step_ab.sh) overrides the in-tree directory
+LIB_PATH = os.path.join(os.environ.get("DY_LIB_DIR") or os.path.join(_HERE, "lib"), "libdedark_yolo.so")
 
 DY_F32, DY_BF16, DY_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2

@@ -6,12 +6,22 @@
 // walks pixels with a grid stride, two pixels in flight per iteration; a wave covers 64 consecutive channel groups of one
 // pixel row (1 KiB contiguous when C >= 512 bf16) or several adjacent pixels for narrower tensors.
 #include <stdlib.h>
+#include <type_traits>
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
 namespace {
 
 constexpr int NT = 256;
+// NTS = non-temporal loads and stores: tensors beyond ~128 MB stream through the caches once (+8-12 % on 210-840 MB tensors, same
+// box); smaller ones were written by the producing kernel a moment ago and are still in the Infinity Cache -- non-temporal reads of a
+// 105 MB tensor are 9-13 % SLOWER (tools/gpu/bn_ab.sh, profiles/r03_bn_nontemporal_ab.txt)
+template <typename T, bool NTS> __device__ inline void ld_s(const T* p, float* out) {
+  if constexpr (NTS) ldvec_nt<T>(p, out); else ldvec<T>(p, out);
+}
+template <typename T, bool NTS> __device__ inline void st_s(T* p, const float* in) {
+  if constexpr (NTS) stvec_nt<T>(p, in); else stvec<T>(p, in);
+}
 
 // one wave per channel: lane r sums replica r, then a wave reduction (the old one-thread-per-channel loop over the 64
 // replicas was a chain of 128 dependent-latency loads: 10 us for a 64-channel layer)
@@ -62,20 +72,28 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 __device__ inline float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // The f32 instantiation is the parity path and keeps the IEEE expf / division of dy_common.h (a 1e-6 relative sigmoid error
 // is amplified past the 1e-4 loss-item bound by the 126 small-batch BatchNorm layers of the repo-L golden case).
-template <typename T> __device__ inline float act_f(int act, float u) {
-  if (sizeof(T) == 4) return dy_act(act, u);
-  if (act == DY_ACT_SILU) return u * fast_sigmoid(u);
-  if (act == DY_ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+template <typename T, int ACT> __device__ inline float act_f(float u) {
+  if (sizeof(T) == 4) return dy_act(ACT, u);
+  if (ACT == DY_ACT_SILU) return u * fast_sigmoid(u);
+  if (ACT == DY_ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
   return u;
 }
-template <typename T> __device__ inline float dact_f(int act, float u) {
-  if (sizeof(T) == 4) return dy_dact(act, u);
-  if (act == DY_ACT_SILU) {
+template <typename T, int ACT> __device__ inline float dact_f(float u) {
+  if (sizeof(T) == 4) return dy_dact(ACT, u);
+  if (ACT == DY_ACT_SILU) {
     const float s = fast_sigmoid(u);
     return s * (1.0f + u * (1.0f - s));
   }
-  if (act == DY_ACT_LEAKY) return u > 0.f ? 1.0f : 0.1f;
+  if (ACT == DY_ACT_LEAKY) return u > 0.f ? 1.0f : 0.1f;
   return 1.0f;
+}
+// The activation is a launch parameter, the element loops want it at compile time: with a run-time switch inside them every ELEMENT went
+// through four scalar branches and its exp -> add -> rcp -> mul chain ran alone in its basic block (s_nop between the transcendentals, no
+// second element to overlap with).  The loop is instantiated once per activation inside the kernel and picked in front of it.
+template <typename F> __device__ inline void with_act(int act, F&& f) {
+  if (act == DY_ACT_SILU) f(std::integral_constant<int, DY_ACT_SILU>{});
+  else if (act == DY_ACT_LEAKY) f(std::integral_constant<int, DY_ACT_LEAKY>{});
+  else f(std::integral_constant<int, DY_ACT_NONE>{});
 }
 
 struct Map {           // thread -> (channel group, first pixel, pixel stride)
@@ -102,7 +120,7 @@ __device__ inline Map make_map(int C, int cgb, int rows) {
 // Per-channel constants are staged once per block in LDS (coalesced loads by the first threads) and copied to registers.
 // U = pixels in flight per thread.  More is not better: the 7 per-channel constants x VE already take 56 VGPRs in the backward
 // kernels, and occupancy beats per-thread ILP for these streams (bn_bench: apply on 64ch x 6.5 M px 531 us at U=4, 487 us at U=1).
-template <typename T, int U>
+template <typename T, int U, bool NTS>
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z, long z_ld, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, const T* __restrict__ res,
                                                          long res_ld, T* __restrict__ y, long y_ld, long pixels, int C, int cgb,
@@ -124,33 +142,41 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ z,
     sc[e] = lds[m.cl + e];
     sh[e] = lds[nch + m.cl + e];
   }
-  for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
-    float v[U][VE], r[U][VE];
+  with_act(act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    auto loop = [&](auto resc) {
+      constexpr bool RES = decltype(resc)::value;
+      for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+        float v[U][VE], r[U][VE];
 #pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const long p = p0 + k * m.step;
-      if (p < pixels) {
-        ldvec<T>(z + p * z_ld + m.c, v[k]);
-        if (res) ldvec<T>(res + p * res_ld + m.c, r[k]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const long p = p0 + k * m.step;
-      if (p < pixels) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          const float o = act_f<T>(act, v[k][e] * sc[e] + sh[e]);
-          v[k][e] = res ? o + r[k][e] : o;
+        for (int k = 0; k < U; ++k) {
+          const long p = p0 + k * m.step;
+          if (p < pixels) {
+            ld_s<T, NTS>(z + p * z_ld + m.c, v[k]);
+            if (RES) ld_s<T, NTS>(res + p * res_ld + m.c, r[k]);
+          }
         }
-        stvec<T>(y + p * y_ld + m.c, v[k]);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const long p = p0 + k * m.step;
+          if (p < pixels) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+              const float o = act_f<T, ACT>(v[k][e] * sc[e] + sh[e]);
+              v[k][e] = RES ? o + r[k][e] : o;
+            }
+            st_s<T, NTS>(y + p * y_ld + m.c, v[k]);
+          }
+        }
       }
-    }
-  }
+    };
+    if (res) loop(std::true_type{});
+    else loop(std::false_type{});
+  });
 }
 
 // backward pass 1: per-channel sums of g and g*zhat
-template <typename T, int U>
+template <typename T, int U, bool NTS>
 __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
                                                                 long z_ld, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
@@ -182,29 +208,32 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
       s1[e] = 0.f;
       s2[e] = 0.f;
     }
-    for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
-      float g[U][VE], zz[U][VE];
+    with_act(act, [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+      for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+        float g[U][VE], zz[U][VE];
 #pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const long p = p0 + k * m.step;
-        if (p < pixels) {
-          ldvec<T>(dy + p * dy_ld + m.c, g[k]);
-          ldvec<T>(z + p * z_ld + m.c, zz[k]);
+        for (int k = 0; k < U; ++k) {
+          const long p = p0 + k * m.step;
+          if (p < pixels) {
+            ld_s<T, NTS>(dy + p * dy_ld + m.c, g[k]);
+            ld_s<T, NTS>(z + p * z_ld + m.c, zz[k]);
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const long p = p0 + k * m.step;
-        if (p < pixels) {
+        for (int k = 0; k < U; ++k) {
+          const long p = p0 + k * m.step;
+          if (p < pixels) {
 #pragma unroll
-          for (int e = 0; e < VE; ++e) {
-            const float ge = g[k][e] * dact_f<T>(act, zz[k][e] * sc[e] + sh[e]);
-            s1[e] += ge;
-            s2[e] += ge * ((zz[k][e] - mu[e]) * is[e]);
+            for (int e = 0; e < VE; ++e) {
+              const float ge = g[k][e] * dact_f<T, ACT>(zz[k][e] * sc[e] + sh[e]);
+              s1[e] += ge;
+              s2[e] += ge * ((zz[k][e] - mu[e]) * is[e]);
+            }
           }
         }
       }
-    }
+    });
     // block reduction without atomics (the LDS float atomics serialised up to `rows` deep on every channel and made the order of
     // the additions, hence the last bits of the sums, depend on wave arrival): each thread parks its VE partial sums, the first
     // 2 * nch threads then add the `rows` values of one channel in a fixed order
@@ -231,7 +260,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const T* __restri
 }
 
 // backward pass 2: dz = k1*g - (K2*zhat + K3) with k1 = gamma*invstd, K2 = k1*sum(g*zhat)/M, K3 = k1*sum(g)/M
-template <typename T, int U>
+template <typename T, int U, bool NTS>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ z,
                                                                long z_ld, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ mean,
@@ -282,29 +311,32 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
     k2[e] = lds[5 * nch + m.cl + e];
     k3[e] = lds[6 * nch + m.cl + e];
   }
-  for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
-    float g[U][VE], zz[U][VE];
+  with_act(act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    for (long p0 = m.first; p0 < pixels; p0 += U * m.step) {
+      float g[U][VE], zz[U][VE];
 #pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const long p = p0 + k * m.step;
-      if (p < pixels) {
-        ldvec<T>(dy + p * dy_ld + m.c, g[k]);
-        ldvec<T>(z + p * z_ld + m.c, zz[k]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const long p = p0 + k * m.step;
-      if (p < pixels) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          const float ge = g[k][e] * dact_f<T>(act, zz[k][e] * sc[e] + sh[e]);
-          g[k][e] = k1[e] * ge - (k2[e] * ((zz[k][e] - mu[e]) * is[e]) + k3[e]);
+      for (int k = 0; k < U; ++k) {
+        const long p = p0 + k * m.step;
+        if (p < pixels) {
+          ld_s<T, NTS>(dy + p * dy_ld + m.c, g[k]);
+          ld_s<T, NTS>(z + p * z_ld + m.c, zz[k]);
         }
-        stvec<T>(dz + p * dz_ld + m.c, g[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const long p = p0 + k * m.step;
+        if (p < pixels) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            const float ge = g[k][e] * dact_f<T, ACT>(zz[k][e] * sc[e] + sh[e]);
+            g[k][e] = k1[e] * ge - (k2[e] * ((zz[k][e] - mu[e]) * is[e]) + k3[e]);
+          }
+          st_s<T, NTS>(dz + p * dz_ld + m.c, g[k]);
+        }
       }
     }
-  }
+  });
 }
 
 struct Geo { int cgb, rows; dim3 grid; };
@@ -383,7 +415,7 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   hipStream_t st = (hipStream_t)stream;
   const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
   dy_note_kernel("bn_act_fwd_kernel");
-#define FWD(T_, U_) bn_act_fwd_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
+#define FWD(T_, U_) bn_act_fwd_kernel<T_, U_, (U_ == 4)><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
                                                                     (T_*)y, y_ld, pixels, C, g.cgb, g.rows)
   if (dtype == DY_F32) { if (big) FWD(float, 4); else FWD(float, 2); }
   else if ((dtype) == DY_F16) { if (big) FWD(f16_t, 4); else FWD(f16_t, 2); }
@@ -405,28 +437,13 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int64_t dy_ld, const void* z
   size_t shm = (4 + 2 * (size_t)g.rows) * g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   dy_note_kernel("bn_act_bwd_reduce_kernel");
-  static const int env_u = dy_env("DY_BN_REDUCE_U") ? atoi(dy_env("DY_BN_REDUCE_U")) : 0;      // (DIAG builds: sweep aid)
-  if (env_u == 4 && dtype == DY_BF16) {
-    bn_act_bwd_reduce_kernel<bf16_t, 4><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
-    DY_LAUNCH_CHECK();
-    return 0;
-  }
-  if (env_u == 1 && dtype == DY_BF16) {
-    bn_act_bwd_reduce_kernel<bf16_t, 1><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
-    DY_LAUNCH_CHECK();
-    return 0;
-  }
-  if (dtype == DY_F32)
-    bn_act_bwd_reduce_kernel<float, 2><<<g.grid, NT, shm, st>>>((const float*)dy, dy_ld, (const float*)z, z_ld, scale, shift, mean,
-                                                                invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
-  else if ((dtype) == DY_F16)
-    bn_act_bwd_reduce_kernel<f16_t, 2><<<g.grid, NT, shm, st>>>((const f16_t*)dy, dy_ld, (const f16_t*)z, z_ld, scale, shift,
-                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
-  else
-    bn_act_bwd_reduce_kernel<bf16_t, 2><<<g.grid, NT, shm, st>>>((const bf16_t*)dy, dy_ld, (const bf16_t*)z, z_ld, scale, shift,
-                                                                 mean, invstd, act, has_bn, sums, pixels, C, g.cgb, g.rows);
+  const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+#define REDUCE(T_, N_) bn_act_bwd_reduce_kernel<T_, 2, N_><<<g.grid, NT, shm, st>>>((const T_*)dy, dy_ld, (const T_*)z, z_ld, scale, shift, mean, invstd, \
+                                                                                   act, has_bn, sums, pixels, C, g.cgb, g.rows)
+  if (dtype == DY_F32) { if (big) REDUCE(float, true); else REDUCE(float, false); }
+  else if (dtype == DY_F16) { if (big) REDUCE(f16_t, true); else REDUCE(f16_t, false); }
+  else { if (big) REDUCE(bf16_t, true); else REDUCE(bf16_t, false); }
+#undef REDUCE
   DY_LAUNCH_CHECK();
   return 0;
 }
@@ -446,7 +463,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int64_t dy_ld, const void* z,
   hipStream_t st = (hipStream_t)stream;
   const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
   dy_note_kernel("bn_act_bwd_apply_kernel");
-#define APPLY(T_, U_) bn_act_bwd_apply_kernel<T_, U_><<<g.grid, NT, shm, st>>>((const T_*)dy, dy_ld, (const T_*)z, z_ld, scale, shift, mean, invstd, \
+#define APPLY(T_, U_) bn_act_bwd_apply_kernel<T_, U_, (U_ == 1)><<<g.grid, NT, shm, st>>>((const T_*)dy, dy_ld, (const T_*)z, z_ld, scale, shift, mean, invstd, \
                                                                             gamma, act, has_bn, sums, (T_*)dz, dz_ld, dgamma, dbeta, pixels, \
                                                                             pixels > 0 ? pixels : 1, C, g.cgb, g.rows)
   if (dtype == DY_F32) { if (big) APPLY(float, 1); else APPLY(float, 2); }

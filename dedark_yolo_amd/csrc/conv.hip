@@ -793,21 +793,34 @@ __device__ inline void pack_chunk(const dy_pack_item& it, float (&tile)[PACK_TIL
     }
   }
   __syncthreads();
-  const int n_out = PACK_TILE * PACK_TILE * tc;
-  if (!it.transposed) {                            // packed[co][tap][ci]: 32 consecutive ci per (co, tap)
-    for (int i = tid; i < n_out; i += 256) {
-      const int cl = i & (PACK_TILE - 1), rt = i >> 5;
-      const int r = rt / tc, t = rt - r * tc;
-      const int co = co0 + r, ci = ci0 + cl;
-      if (co < it.Cout_pad && ci < it.Cin_pad) pack_store(it, ((long)co * T + t0 + t) * it.Cin_pad + ci, tile[r][cl * PACK_TAPS + t]);
+  // write: 16 bytes per thread (8 consecutive elements of the destination's contiguous dimension in the 16-bit dtypes, 4 in f32; the
+  // padded extents are multiples of that vector, so a group is either whole or absent).  One 2-byte store per thread made this phase
+  // 36 store instructions per thread and tile.
+  const int VE = it.dtype == DY_F32 ? 4 : 8, GP = PACK_TILE / VE;           // elements per store, groups per 32-wide run
+  const int n_vec = PACK_TILE * GP * tc;
+  for (int i = tid; i < n_vec; i += 256) {
+    const int g = i % GP, q = i / GP;
+    const int a = q / tc, t = q - a * tc;                  // a = tile row (co) of a plain pack, tile column (ci) of a transposed one
+    float v[8];
+    long o;
+    bool ok;
+    if (!it.transposed) {                                  // packed[co][tap][ci]
+      const int co = co0 + a, ci = ci0 + g * VE;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = e < VE ? tile[a][(g * VE + e) * PACK_TAPS + t] : 0.f;
+      ok = co < it.Cout_pad && ci < it.Cin_pad;
+      o = ((long)co * T + t0 + t) * it.Cin_pad + ci;
+    } else {                                               // packed[ci][tap][co]
+      const int ci = ci0 + a, co = co0 + g * VE;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = e < VE ? tile[g * VE + e][a * PACK_TAPS + t] : 0.f;
+      ok = co < it.Cout_pad && ci < it.Cin_pad;
+      o = ((long)ci * T + t0 + t) * it.Cout_pad + co;
     }
-  } else {                                         // packed[ci][tap][co]: 32 consecutive co per (ci, tap)
-    for (int i = tid; i < n_out; i += 256) {
-      const int r = i & (PACK_TILE - 1), ct = i >> 5;
-      const int cl = ct / tc, t = ct - cl * tc;
-      const int co = co0 + r, ci = ci0 + cl;
-      if (co < it.Cout_pad && ci < it.Cin_pad) pack_store(it, ((long)ci * T + t0 + t) * it.Cout_pad + co, tile[r][cl * PACK_TAPS + t]);
-    }
+    if (!ok) continue;
+    if (it.dtype == DY_F32) stvec<float>((float*)it.packed + o, v);
+    else if (it.dtype == DY_F16) stvec<f16_t>((f16_t*)it.packed + o, v);
+    else stvec<bf16_t>((bf16_t*)it.packed + o, v);
   }
   __syncthreads();
 }

@@ -147,11 +147,16 @@ template <> __device__ inline void stvec<float>(float* p, const float* in) {
   f32x4 v = {in[0], in[1], in[2], in[3]};
   *reinterpret_cast<f32x4*>(p) = v;
 }
+// two floats -> one dword of bf16 (v_cvt_pk_bf16_f32: one instruction per PAIR, round-to-nearest-even, NaN stays NaN)
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
+}
 template <> __device__ inline void stvec<bf16_t>(bf16_t* p, const float* in) {
   u32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    v[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
   *reinterpret_cast<u32x4*>(p) = v;
 }
 
@@ -160,6 +165,46 @@ template <> __device__ inline void stvec<f16_t>(f16_t* p, const float* in) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (f16_t)in[i];
   *reinterpret_cast<f16x8*>(p) = v;
+}
+
+// streaming forms (the BatchNorm passes): non-temporal loads / stores of the same 16 bytes
+template <typename T> __device__ inline void ldvec_nt(const T* p, float* out) {
+  if constexpr (sizeof(T) == 4) {
+    // (as a u32x4 load whose lanes are bit-cast one by one, hipcc of ROCm 7.2 split this into four dword loads from the SAME address)
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+  } else {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    if constexpr (__is_same(T, f16_t)) {
+      const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = (float)h[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        out[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+        out[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+      }
+    }
+  }
+}
+template <typename T> __device__ inline void stvec_nt(T* p, const float* in) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 v = {in[0], in[1], in[2], in[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  } else {
+    u32x4 v;
+    if constexpr (__is_same(T, f16_t)) {
+      f16x8 h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = (f16_t)in[i];
+      v = __builtin_bit_cast(u32x4, h);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  }
 }
 
 // ---- activations ---------------------------------------------------------------------------------------------

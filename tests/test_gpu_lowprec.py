@@ -207,7 +207,9 @@ def test_l_graph_low_precision_vs_fp32_oracle(dtype):
     (_StorageEmulation; forward tensors only -- its backward runs in fp32, the product also stores gradients in 16 bit).
     Product error <= 1.5 x the emulation's error (+ 1e-2); gradient direction no worse than the emulation's by more than 0.15
     (measured bf16: maps 0.630 vs 0.624, cosine 0.16 vs 0.27 -- both essentially decorrelated from fp32 on this graph; fp16:
-    0.115 vs 0.14, cosine 0.90 vs 0.9).  The training loss is checked against the fp32 oracle (5 %)."""
+    0.115 vs 0.14, cosine 0.90 vs 0.9).  The training loss follows the same logic: maps that differ from fp32 by 60 % (bf16) put the
+    criterion's discrete assignment somewhere else, so its distance from the fp32 oracle is bounded by 1.5 x the distance of the
+    storage emulation's loss (+ 5 % of the oracle's value; fp16, whose maps stay within 12 %, is inside the 5 % alone)."""
     _supported(dtype)
     import dedark_yolo_amd as dy
     from parity_helpers import model_parity_case
@@ -224,7 +226,20 @@ def test_l_graph_low_precision_vs_fp32_oracle(dtype):
     r = model_parity_case("yolov8.yaml", "l", None, 404, 256, 4, [3, 2, 5, 1], dtype=dtype)
     print(f"   training loss {r['loss']:.4f} vs fp32 oracle {r['oracle_loss']:.4f}")
     assert r["grad_finite"] and r["n_nograd"] == 0
-    assert abs(r["loss"] - r["oracle_loss"]) <= 0.05 * abs(r["oracle_loss"])
+    # the same step on fp32 kernels with every stored tensor rounded to `dtype`
+    from parity_helpers import build_models
+    dy.set_compute_dtype(torch.float32)
+    model, _ = build_models("yolov8.yaml", "l", None, 404)
+    batch = make_batch(405, 4, 256, [3, 2, 5, 1])
+    gb = dict(batch)
+    gb["img"] = batch["img"].pow(3.0).cuda()
+    gb["recovery_loss_batch"] = torch.tensor(0.0123, device="cuda")
+    model.train()
+    with _emulated_storage(model, dtype):
+        l_emu = float(model(gb)[0])
+    d_prod, d_emu = abs(r["loss"] - r["oracle_loss"]), abs(l_emu - r["oracle_loss"])
+    print(f"   storage emulation {l_emu:.4f}: distance from the oracle {d_emu:.2f} (product {d_prod:.2f})")
+    assert d_prod <= 1.5 * d_emu + 0.05 * abs(r["oracle_loss"]), (r["loss"], l_emu, r["oracle_loss"])
 
 
 import contextlib
