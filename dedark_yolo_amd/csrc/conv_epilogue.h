@@ -23,7 +23,10 @@ template <int BM, int BN>
 constexpr int image_bytes() { return BN * pitch<BM>(); }
 
 template <typename T16 = bf16_t>
-__device__ inline uint32_t pack2(float a, float b) { return (uint32_t)cvt16<T16>(a) | ((uint32_t)cvt16<T16>(b) << 16); }
+__device__ inline uint32_t pack2(float a, float b) {
+  if constexpr (__is_same(T16, bf16_t)) return pack_bf16x2(a, b);           // one v_cvt_pk_bf16_f32 for the pair
+  else return (uint32_t)cvt16<T16>(a) | ((uint32_t)cvt16<T16>(b) << 16);
+}
 
 // Store phase: the transposed image [BN cols][BM rows] (pitch<BM>() bytes per column) -> HBM.  Unit = 16 pixels x 32 channels
 // per wave instruction; NW waves share the units.  The caller has synchronised the block after writing the image.
