@@ -182,6 +182,7 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_live[j] = q0 + wn * (BQ / 2) + j * 32 < p.Cout;
 
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   if (nsteps > 0) issue(0);
   if (NSTAGE > 2 && nsteps > 1) issue(1);
   for (int s = 0; s < nsteps; ++s) {
@@ -189,28 +190,37 @@ __global__ __launch_bounds__(BP * 2) void wgrad_kernel(P p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + NSTAGE - 1 < nsteps) issue((s + NSTAGE - 1) % NSTAGE);
-    const char* stage = smem + (s % NSTAGE) * STAGE;
+    // Transposing reads as inline asm: hipcc (ROCm 7.2) orders the ds_read_tr16 builtin behind every pending LDS DMA with an
+    // s_waitcnt vmcnt(0) -- right behind the issue() above, so the stage just sent out had to land before the current one was computed
+    // and the ring never had anything in flight.  The counts are ours: lgkmcnt(0) in front of the MFMAs of a 16-pixel slice.
+    const unsigned stage = lds0 + (unsigned)((s % NSTAGE) * STAGE);
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {                         // 16 pixels per MFMA
-      s16x8 af[TM], bf[TN];
+      uint2 alo[TM], ahi[TM], blo[TN], bhi[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(stage + a_adr[i][0] + sl * 4096));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(stage + a_adr[i][1] + sl * 4096));
-        af[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[i]) : "v"(stage + (unsigned)a_adr[i][0]), "n"(sl * 4096) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(stage + (unsigned)a_adr[i][1]), "n"(sl * 4096) : "memory");
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(stage + b_adr[j][0] + sl * 4096));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(stage + b_adr[j][1] + sl * 4096));
-        bf[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(blo[j]) : "v"(stage + (unsigned)b_adr[j][0]), "n"(sl * 4096) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[j]) : "v"(stage + (unsigned)b_adr[j][1]), "n"(sl * 4096) : "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = u32x4{alo[i].x, alo[i].y, ahi[i].x, ahi[i].y};
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = u32x4{blo[j].x, blo[j].y, bhi[j].x, bhi[j].y};
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           if (a_live[i] && b_live[j])
             acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

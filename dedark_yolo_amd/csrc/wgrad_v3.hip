@@ -75,6 +75,7 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int XB = p.XW * PXB, ZB = p.PW * ZPB;           // bytes per x / dz row buffer
   const int co0 = blockIdx.y * CO;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   char* xring = smem;                                   // 4 x rows
   char* zring = smem + 4 * XB;                          // 2 dz rows
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -119,30 +120,40 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
       load_row<CI, NW>(p.x, p.x_ld, 0, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
       load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero, col0, col0, zhi);
     }
-    const char* xa[3];
+    // Transposing reads as inline asm: hipcc (ROCm 7.2) orders the ds_read_tr16 builtin behind every pending LDS DMA with an
+    // s_waitcnt vmcnt(0) -- here in front of the first read of every slice, i.e. the prefetch of the next row had to land completely
+    // before any MFMA of the current row (an exposed HBM round trip per image row: ~0.5 us of MFMA work per row waited 1-2 us).  The
+    // counts are ours: lgkmcnt(0) in front of the MFMAs of a slice, vmcnt(0) + barrier at the end of the row.
+    unsigned xa[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xa[i] = xring + ((h + a_kh[i]) & 3) * XB + a_off[i];       // x row h + kh - 1
-    const char* zb = zring + (h & 1) * ZB;
+    for (int i = 0; i < 3; ++i) xa[i] = lds0 + (unsigned)(((h + a_kh[i]) & 3) * XB + a_off[i]);       // x row h + kh - 1
+    const unsigned zb = lds0 + (unsigned)(4 * XB + (h & 1) * ZB);
     for (int s = 0; s < nslices; ++s) {
-      const int so = s * 16 * PXB, sz = s * 16 * ZPB;
-      s16x8 af[3], bf[2];
+      const unsigned so = s * 16 * PXB, sz = s * 16 * ZPB;
+      uint2 alo[3], ahi[3], blo[2], bhi[2];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xa[i] + so));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xa[i] + so + 4 * PXB));
-        af[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[i]) : "v"(xa[i] + so) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(xa[i] + so), "n"(4 * PXB) : "memory");
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + sz));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + b_off[j] + sz + 4 * ZPB));
-        bf[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[j]) : "v"(zb + b_off[j] + sz) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[j]) : "v"(zb + b_off[j] + sz), "n"(4 * ZPB) : "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 af[3], bf[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) af[i] = u32x4{alo[i].x, alo[i].y, ahi[i].x, ahi[i].y};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = u32x4{blo[j].x, blo[j].y, bhi[j].x, bhi[j].y};
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
