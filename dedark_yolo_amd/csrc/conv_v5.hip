@@ -378,15 +378,18 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
 // [N*H*W] source, anything outside the buffer lands as zeros.  What the flattening gets wrong -- taps that cross the left / right /
 // top / bottom border of an image read a real neighbour pixel -- is repaired at the fragment read: a lane whose (pixel, tap) is
 // padding reads a zero row instead (one v_cndmask on the address per fragment, masks precomputed per lane: 9 taps x MB pixels).
-//   BN = 128: 2 bands + 4 weight tiles (66 KiB), weights 3 steps ahead; BN = 64: 3 bands + 7 weight tiles (79 KiB), 6 steps ahead.
+//   BN = 128: 2 bands + 4 weight tiles (66 KiB), weights 3 steps ahead, two blocks per CU.  BN = 64: the same rings (51 KiB) and THREE
+//   co-resident blocks per CU -- a 256 x 64 tile is 0.5 us of MFMA work behind ~10 us of row decode, first DMA round trip and epilogue,
+//   so a third block in flight is worth more than a deeper ring (3 bands + 7 weight tiles, 79 KiB, 6 steps ahead, two blocks per CU:
+//   64->64 at 160x160 217 / 180 us forward / data gradient against 200 / 167; DY_BAND64_NBAND=3 in a DIAG build selects it).
 //   Step t = 3g + tw issues [band g + NBAND - 1 if tw == 0] + weight tile t + DB, DB = 3 (NBAND - 1); its wait leaves exactly the
 //   issues of steps t - DB + 1 .. t - 1 in flight (counted vmcnt, a constant per tw).
 constexpr int BAND_BYTES = 17 * 1024;               // 272 rows of 64 bytes
 
-template <int BN, typename T = bf16_t>
-__global__ __launch_bounds__(256, 2) void band_kernel(const P p) {
+template <int BN, typename T = bf16_t, int NBAND_ = (BN == 64 ? 3 : 2)>
+__global__ __launch_bounds__(256, (BN == 64 && NBAND_ == 2) ? 3 : 2) void band_kernel(const P p) {
   constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, B_LD = BN / 64, B_BYTES = BN * 64;
-  constexpr int NBAND = BN == 64 ? 3 : 2, DB = 3 * (NBAND - 1), NBBUF = DB + 1;
+  constexpr int NBAND = NBAND_, DB = 3 * (NBAND - 1), NBBUF = DB + 1;
   constexpr int OFF_B = NBAND * BAND_BYTES, OFF_ZERO = OFF_B + NBBUF * B_BYTES;
   constexpr int N0 = (DB - 1) * B_LD + 5 * (NBAND - 2), N1 = (DB - 1) * B_LD + 5 * (NBAND - 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -645,6 +648,10 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
   constexpr int BAND128 = 2 * v5::BAND_BYTES + 4 * 128 * 64 + 64, BAND64 = 3 * v5::BAND_BYTES + 7 * 64 * 64 + 64;
   constexpr int SB128 = BAND128 > EPI128 ? BAND128 : EPI128, SB64 = BAND64 > EPI64 ? BAND64 : EPI64;
+  // 64-wide tiles with the 128-wide variant's shallower rings (2 bands + 4 weight tiles = 51 KiB): THREE co-resident blocks per CU
+  constexpr int BAND64S = 2 * v5::BAND_BYTES + 4 * 64 * 64 + 64, SB64S = BAND64S > EPI64 ? BAND64S : EPI64;
+  static_assert(3 * SB64S <= 160 * 1024, "three blocks per CU");
+  static const int band64_nband = dy_env("DY_BAND64_NBAND") ? atoi(dy_env("DY_BAND64_NBAND")) : 2;
   static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024 && 2 * SB128 <= 160 * 1024 && 2 * SB64 <= 160 * 1024, "two blocks per CU");
   // 3x3 / stride 1 / pad 1 on an unchanged pixel grid: the band kernel
   static const bool no_band = dy_env("DY_NO_CONV_BAND") != nullptr;
@@ -660,6 +667,8 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64S);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, f16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64S);
     if (e != hipSuccess) {
       dy_set_error("conv_v5: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 3;
@@ -671,6 +680,10 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     dy_note_kernel("v5::band_kernel<128>");
     if (f16) v5::band_kernel<128, f16_t><<<p.nblk, 256, SB128, (hipStream_t)stream>>>(p);
     else v5::band_kernel<128, bf16_t><<<p.nblk, 256, SB128, (hipStream_t)stream>>>(p);
+  } else if (band && band64_nband == 2) {
+    dy_note_kernel("v5::band_kernel<64>");
+    if (f16) v5::band_kernel<64, f16_t, 2><<<p.nblk, 256, SB64S, (hipStream_t)stream>>>(p);
+    else v5::band_kernel<64, bf16_t, 2><<<p.nblk, 256, SB64S, (hipStream_t)stream>>>(p);
   } else if (band) {
     dy_note_kernel("v5::band_kernel<64>");
     if (f16) v5::band_kernel<64, f16_t><<<p.nblk, 256, SB64, (hipStream_t)stream>>>(p);
