@@ -177,8 +177,10 @@ __device__ __forceinline__ void epilogue(const P& p, f32x4 (&acc)[MB][4], char* 
 }
 
 // BN = 128: waves 2 (M) x 2 (N), wave tile 128 x 64.  BN = 64 (the 64-channel layers): waves 4 x 1, wave tile 64 x 64.
-template <int BN, typename T = bf16_t>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
+// SLIM (BN = 64 only): a two-stage ring of single K-steps (40 KiB) and FOUR co-resident blocks per CU instead of four stages in pairs
+// (80 KiB) and two blocks: the 64-wide tiles of the high-resolution layers are 0.5 us of MFMA work behind ~10 us of fixed per-tile cost
+template <int BN, typename T = bf16_t, bool SLIM = false>
+__global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P p) {
   constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, NB = 4, STAGE = A_BYTES + BN * 64, B_LD = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -333,6 +335,20 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const P p) {
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == 2 * STAGE ? 0 : cur + STAGE;
       fill = fill == 2 * STAGE ? 0 : fill + STAGE;
+    }
+  } else if constexpr (SLIM) {
+    issue(0);
+    advance();
+    int cur = 0;
+    for (int kt = 0; kt < p.nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-step kt has landed (nothing younger is in flight)
+      __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading K-step kt - 1
+      __builtin_amdgcn_sched_barrier(0);
+      issue(cur ? 0 : STAGE);                              // K-step kt + 1 into the other stage
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, walk);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur ? 0 : STAGE;
     }
   } else {
     // 64-wide tiles: a wave has only 16 MFMAs per K-step, less than the fixed cost of a step (wait + barrier + DMA issue), so the
@@ -646,6 +662,9 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   constexpr int RING128 = v5::NSTAGE * (v5::A_BYTES + 128 * 64), EPI128 = dy_epi::row_image_bytes<v5::BM, 128>();
   constexpr int RING64 = 4 * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
   constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
+  constexpr int RING64S = 2 * (v5::A_BYTES + 64 * 64), SH64S = RING64S > EPI64 ? RING64S : EPI64;
+  static_assert(4 * SH64S <= 160 * 1024, "four blocks per CU");
+  static const bool slim64 = !(dy_env("DY_CONV64_SLIM") && atoi(dy_env("DY_CONV64_SLIM")) == 0);
   constexpr int BAND128 = 2 * v5::BAND_BYTES + 4 * 128 * 64 + 64, BAND64 = 3 * v5::BAND_BYTES + 7 * 64 * 64 + 64;
   constexpr int SB128 = BAND128 > EPI128 ? BAND128 : EPI128, SB64 = BAND64 > EPI64 ? BAND64 : EPI64;
   // 64-wide tiles with the 128-wide variant's shallower rings (2 bands + 4 weight tiles = 51 KiB): THREE co-resident blocks per CU
@@ -663,6 +682,8 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64S);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::conv_kernel<64, f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SH64S);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<128, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<64, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v5::band_kernel<128, f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB128);
@@ -692,6 +713,10 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
     dy_note_kernel("v5::conv_kernel<128>");
     if (f16) v5::conv_kernel<128, f16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
     else v5::conv_kernel<128, bf16_t><<<p.nblk, 256, SH128, (hipStream_t)stream>>>(p);
+  } else if (slim64) {
+    dy_note_kernel("v5::conv_kernel<64>");
+    if (f16) v5::conv_kernel<64, f16_t, true><<<p.nblk, 256, SH64S, (hipStream_t)stream>>>(p);
+    else v5::conv_kernel<64, bf16_t, true><<<p.nblk, 256, SH64S, (hipStream_t)stream>>>(p);
   } else {
     dy_note_kernel("v5::conv_kernel<64>");
     if (f16) v5::conv_kernel<64, f16_t><<<p.nblk, 256, SH64, (hipStream_t)stream>>>(p);
