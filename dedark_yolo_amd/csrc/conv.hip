@@ -25,6 +25,10 @@ bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode);
 int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream);
 bool dy_conv_v4_eligible(const dy_conv_desc* d, int mode);
 int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream);
+bool dy_conv_v5_classes_eligible(const dy_conv_desc* classes, int ncls);
+int dy_conv_v5_launch_classes(const dy_conv_desc* classes, int ncls, void* stream);
+bool dy_conv_v4_classes_eligible(const dy_conv_desc* classes, int ncls);
+int dy_conv_v4_launch_classes(const dy_conv_desc* classes, int ncls, void* stream);
 bool dy_conv_v3_eligible(const dy_conv_desc* d);
 int dy_conv_v3_launch(const dy_conv_desc* d, int mode, void* stream);
 // pipelined bf16 weight gradient (wgrad_v2.hip)
@@ -1060,6 +1064,10 @@ static int dgrad_dispatch(const dy_conv_desc* d, void* stream, bool* added) {
         // ... where the classes are small: once a class alone fills the chip (C3: 256->512 at 80x80, B = 64, 400 tiles of
         // 256x256 per class) one launch is SLOWER than four (560 vs 449 us) -- the short-K classes' blocks then crowd out the long ones
         const long class_tiles = dy_cdiv((long)r[0].N * r[0].Hd * r[0].Wd, 256);
+        // the large-tile kernels: ONE launch whose block order hands every XCD its share of every class, longest tiles first (four
+        // launches each end in their own partial round of tiles: 512->512 at 40x40, B = 64: 286 -> 127 us, tools/gpu/s2_fanout.sh)
+        if (dy_conv_v4_classes_eligible(r, nc)) return dy_conv_v4_launch_classes(r, nc, stream);
+        if (dy_conv_v5_classes_eligible(r, nc)) return dy_conv_v5_launch_classes(r, nc, stream);
         if (all_v2 && class_tiles <= 256) return dy_conv_v2_launch_classes(r, nc, stream);
         if (none_v2) {
           bool thin = true;

@@ -69,6 +69,11 @@ struct P {
   int n_full, rb_tail;           // blocks [0, n_full) are 256-row tiles; the rest are tail tiles of 64 * rb_tail rows (see v4_launch)
   const char* add_src;           // optional addend view of a data gradient (dy_conv_desc.add_src)
   long add_src_ld;
+  // > 1: the parity classes of a stride-2 data gradient in ONE launch (forward-style problems over the same dz and weights that differ
+  // in destination offset, grid extent, tap subset and pad).  cls[c].blk0 = first slot of class c in every XCD's block sequence,
+  // cls[c]._r = its slots per XCD: each XCD works through its eighth of class 0 (the one with the most taps), then of class 1, ...
+  int ncls;
+  DyParityCls cls[4];
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -448,6 +453,29 @@ __device__ __forceinline__ void conv_tile(const P& p, char* smem, const long m0,
 template <int ABL, typename T = bf16_t>
 __global__ __launch_bounds__(512) void conv_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.ncls > 1) {
+    // several problems in one launch: this block's class replaces the launch-wide geometry.  Four launches of 1-, 2-, 2- and 4-tap
+    // problems each end in their own partial round of tiles (100-400 tiles on 256 CUs, four times); together the classes fill the
+    // rounds, and the long tiles go first.  The XCD gets an equal share of EVERY class (a plain xcd_remap over the class-major order
+    // would hand the 4-tap tiles to two XCDs and the 1-tap tiles to two others).
+    const int x = blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < p.ncls && i >= p.cls[k].blk0) c = k;
+    const DyParityCls& k = p.cls[c];
+    const int tile = x * k._r + (i - k.blk0);
+    const int tiles = (int)((k.M + BM - 1) / BM) * p.tiles_n;
+    if (tile >= tiles) return;                       // (block-uniform: up to 7 surplus blocks per class)
+    P q = p;
+    q.dst = k.dst; q.M = k.M; q.Hd = k.Hd; q.Wd = k.Wd; q.KH = k.KH; q.KW = k.KW;
+    q.dh0 = -k.pad; q.dw0 = -k.pad; q.kh0 = k.kh0; q.kw0 = k.kw0;
+    q.nk = k.Ktot / BK;
+    q.a_min = -(k.pad * p.Ws + k.pad) * (int)p.src_ld * 2;
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    conv_tile<ABL, T, 4>(q, smem, (long)tile_m * BM, tile_n * BN, tile_m);
+    return;
+  }
   // full tiles first (they are dispatched first), each population spread over the XCDs on its own
   const bool tail = (int)blockIdx.x >= p.n_full;
   const int bid = tail ? p.n_full + xcd_remap(blockIdx.x - p.n_full, p.nblk - p.n_full) : xcd_remap(blockIdx.x, p.n_full);
@@ -544,8 +572,8 @@ static void v4_split(long M, int tiles_n, int& n_full, int& rb_tail, int& nblk) 
 }
 
 template <int ABL, typename T = bf16_t>
-static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_variant = 0) {
-  const int variant = force_variant ? force_variant : v4_variant(d, mode);
+static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_variant = 0, const dy_conv_desc* classes = nullptr, int ncls = 0) {
+  const int variant = force_variant ? force_variant : (ncls > 1 ? 256 : v4_variant(d, mode));
   DY_CHECK(variant != 0, "conv_v4: problem not eligible");
   DY_CHECK((long)d->N * d->Hd * d->Wd < (1L << 31), "conv_v4: too many output pixels");
   v4::P p;
@@ -580,6 +608,25 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
   p.dst_img = d->dst_img_stride ? d->dst_img_stride : (long)d->Hd * d->dst_row_stride;
   p.tiles_n = dy_cdiv(d->Cd, variant);
   v4_split(p.M, p.tiles_n, p.n_full, p.rb_tail, p.nblk);
+  p.ncls = 0;
+  if (ncls > 1) {
+    DY_CHECK(ncls <= 4 && mode == 0, "conv_v4: at most 4 forward-style classes");
+    p.ncls = ncls;
+    int slot = 0;
+    for (int c = 0; c < ncls; ++c) {
+      const dy_conv_desc& q = classes[c];
+      DyParityCls& k = p.cls[c];
+      k.dst = (char*)q.dst; k.M = (long)q.N * q.Hd * q.Wd; k.Hd = q.Hd; k.Wd = q.Wd; k.KH = q.KH; k.KW = q.KW; k.pad = q.pad;
+      k.kh0 = q.kh0; k.kw0 = q.kw0; k.Ktot = q.KH * q.KW * q.Cs;
+      DY_CHECK(k.M < (1L << 31), "conv_v4: too many output pixels");
+      const int tiles = (int)dy_cdiv(k.M, (long)v4::BM) * p.tiles_n;
+      k.blk0 = slot;
+      k._r = dy_cdiv(tiles, 8);
+      slot += k._r;
+    }
+    p.nblk = 8 * slot;
+    p.n_full = p.nblk; p.rb_tail = 4;
+  }
   constexpr int EPI256 = dy_epi::row_image_bytes<256, 256>();
   constexpr int SH256 = 2 * v4::BUF > EPI256 ? 2 * v4::BUF : EPI256;
   static_assert(SH256 <= 160 * 1024, "LDS budget");
@@ -601,5 +648,40 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
 #ifndef DY_V4_DIAG_BUILD
 int dy_conv_v4_launch(const dy_conv_desc* d, int mode, void* stream) {
   return d->dtype == DY_F16 ? v4_launch<0, f16_t>(d, mode, stream) : v4_launch<0, bf16_t>(d, mode, stream);
+}
+
+// The parity classes of a stride-2 data gradient (conv.hip: dgrad_dispatch; heaviest class first) as one launch: same dz, same weight
+// pack, same channel counts; taken when the 256-wide channel tiles fit, the heaviest class has a K loop worth a 256 x 256 tile and the
+// classes together fill the chip.  (DY_V4_CLASSES=0 in a DIAG build: one launch per class.)
+bool dy_conv_v4_classes_eligible(const dy_conv_desc* c, int ncls) {
+  static const bool off = dy_env("DY_NO_CONV_V4") != nullptr || (dy_env("DY_V4_CLASSES") && atoi(dy_env("DY_V4_CLASSES")) == 0);
+  if (off || ncls < 2 || ncls > 4) return false;
+  const dy_conv_desc* d = &c[0];
+  if (d->dtype != DY_BF16 && d->dtype != DY_F16) return false;
+  if (!(d->Cs % 64 == 0 && d->KHf > 0 && d->KHf * d->KWf <= 25 && d->stride == 1)) return false;
+  const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
+  const long w_bytes = (long)d->Cd * d->KHf * d->KWf * d->Cs * 2;
+  const long halo = ((long)d->KHf * d->Ws + d->KWf) * d->src_ld * 2;
+  if (!(src_bytes + halo <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return false;
+  const long t256 = (d->Cd + 255) / 256;
+  if (!(d->Cd >= 192 && t256 * 256 * 4 <= (long)d->Cd * 5)) return false;
+  long tiles = 0, kmax = 0;
+  for (int i = 0; i < ncls; ++i) {
+    const dy_conv_desc& q = c[i];
+    if (q.src != d->src || q.w != d->w || q.Cs != d->Cs || q.Cd != d->Cd || q.dtype != d->dtype || q.stride != 1 || q.dil != 1 || q.KHf != d->KHf ||
+        q.KWf != d->KWf || q.kh_step != d->kh_step || q.kw_step != d->kw_step || q.dst_ld != d->dst_ld || q.dst_row_stride != d->dst_row_stride ||
+        q.dst_img_stride != d->dst_img_stride || q.src_ld != d->src_ld || q.accumulate != d->accumulate || q.scale || q.shift || q.stats ||
+        q.act != DY_ACT_NONE)
+      return false;
+    if ((q.dst_ld * 2) % 16 != 0 || ((uintptr_t)q.dst) % 16 != 0 || (q.src_ld * 2) % 16 != 0) return false;
+    tiles += (((long)q.N * q.Hd * q.Wd + 255) / 256) * t256;
+    const long k = (long)q.KH * q.KW * q.Cs;
+    kmax = k > kmax ? k : kmax;
+  }
+  return tiles >= 192 && kmax >= 512;
+}
+
+int dy_conv_v4_launch_classes(const dy_conv_desc* c, int ncls, void* stream) {
+  return c[0].dtype == DY_F16 ? v4_launch<0, f16_t>(&c[0], 0, stream, 0, c, ncls) : v4_launch<0, bf16_t>(&c[0], 0, stream, 0, c, ncls);
 }
 #endif

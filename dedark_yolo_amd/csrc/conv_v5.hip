@@ -67,6 +67,10 @@ struct P {
   int ablate;                    // DY_ABLATE (make DIAG=1 only): 1 A-operand DMA of taps != 0 out of range (no fetch, zeros land),
                                  // 2 every A DMA out of range, 4 every B DMA out of range, 8 no MFMA, 16 no fragment reads,
                                  // 64 taps != 0 issue NO A DMA at all (wait switches to vmcnt(0))
+  // > 1: the parity classes of a stride-2 data gradient in ONE conv_kernel launch (see conv_v4.hip: cls[c].blk0 = first slot of class c in
+  // every XCD's block sequence, cls[c]._r = its slots per XCD)
+  int ncls;
+  DyParityCls cls[4];
 };
 
 __device__ inline int xcd_remap(int bid, int nblk) {
@@ -180,13 +184,30 @@ __device__ __forceinline__ void epilogue(const P& p, f32x4 (&acc)[MB][4], char* 
 // SLIM (BN = 64 only): a two-stage ring of single K-steps (40 KiB) and FOUR co-resident blocks per CU instead of four stages in pairs
 // (80 KiB) and two blocks: the 64-wide tiles of the high-resolution layers are 0.5 us of MFMA work behind ~10 us of fixed per-tile cost
 template <int BN, typename T = bf16_t, bool SLIM = false>
-__global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P p) {
+__global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P pk) {
   constexpr int WN = BN / 64, WM = 4 / WN, MB = BM / WM / 16, NB = 4, STAGE = A_BYTES + BN * 64, B_LD = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = xcd_remap(blockIdx.x, p.nblk);
+  P p = pk;
+  int bid;
+  if (pk.ncls > 1) {                 // several problems in one launch: this block's class replaces the launch-wide geometry (conv_v4.hip)
+    const int x = blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < pk.ncls && i >= pk.cls[k].blk0) c = k;
+    const DyParityCls& k = pk.cls[c];
+    bid = x * k._r + (i - k.blk0);
+    if (bid >= (int)((k.M + BM - 1) / BM) * pk.tiles_n) return;        // (block-uniform: up to 7 surplus blocks per class)
+    p.dst = k.dst; p.M = k.M; p.Hd = k.Hd; p.Wd = k.Wd; p.KH = k.KH; p.KW = k.KW;
+    p.dh0 = -k.pad; p.dw0 = -k.pad; p.kh0 = k.kh0; p.kw0 = k.kw0;
+    p.nk = k.Ktot / BK;
+    p.a_min = -(k.pad * pk.Ws + k.pad) * (int)pk.src_ld * 2;
+  } else {
+    bid = xcd_remap(blockIdx.x, p.nblk);
+  }
   stamp(DY_ABLATE_OF(p), p.nblk, 0);
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const long m0 = (long)tile_m * BM;
@@ -623,7 +644,43 @@ bool dy_conv_v5_eligible(const dy_conv_desc* d, int mode) {
   return d->Cd >= 48 && d->Cd <= 64 && tiles_m >= 256;          // 64-wide tiles for the 64-channel layers
 }
 
-int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
+static int v5_launch(const dy_conv_desc* d, int mode, void* stream, const dy_conv_desc* classes, int ncls);
+
+int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) { return v5_launch(d, mode, stream, nullptr, 0); }
+
+// The parity classes of a stride-2 data gradient (conv.hip: dgrad_dispatch; heaviest class first) as one conv_kernel launch
+// (DY_V5_CLASSES=0 in a DIAG build: one launch per class)
+bool dy_conv_v5_classes_eligible(const dy_conv_desc* c, int ncls) {
+  static const bool off = dy_env("DY_NO_CONV_V5") != nullptr || (dy_env("DY_V5_CLASSES") && atoi(dy_env("DY_V5_CLASSES")) == 0);
+  if (off || ncls < 2 || ncls > 4) return false;
+  const dy_conv_desc* d = &c[0];
+  if (d->dtype != DY_BF16 && d->dtype != DY_F16) return false;
+  if (!(d->Cs % 32 == 0 && d->KHf > 0 && d->KHf * d->KWf <= 25 && d->stride == 1)) return false;
+  const long src_bytes = (((long)d->N * d->Hs * d->Ws - 1) * d->src_ld + d->Cs) * 2;
+  const long w_bytes = (long)d->Cd * d->KHf * d->KWf * d->Cs * 2;
+  const long halo = ((long)d->KHf * d->Ws + d->KWf) * d->src_ld * 2;
+  if (!(src_bytes + halo <= 0x7fffffffL && w_bytes <= 0x3fffffffL)) return false;
+  const long tn = (d->Cd + 127) / 128;
+  const bool wide = d->Cd >= 96 && tn * 128 * 4 <= (long)d->Cd * 5, narrow = d->Cd >= 48 && d->Cd <= 64;
+  if (!wide && !narrow) return false;
+  long tiles = 0;
+  for (int i = 0; i < ncls; ++i) {
+    const dy_conv_desc& q = c[i];
+    if (q.src != d->src || q.w != d->w || q.Cs != d->Cs || q.Cd != d->Cd || q.dtype != d->dtype || q.stride != 1 || q.dil != 1 || q.KHf != d->KHf ||
+        q.KWf != d->KWf || q.kh_step != d->kh_step || q.kw_step != d->kw_step || q.dst_ld != d->dst_ld || q.dst_row_stride != d->dst_row_stride ||
+        q.dst_img_stride != d->dst_img_stride || q.src_ld != d->src_ld || q.accumulate != d->accumulate || q.scale || q.shift || q.stats ||
+        q.act != DY_ACT_NONE)
+      return false;
+    if ((q.dst_ld * 2) % 16 != 0 || ((uintptr_t)q.dst) % 16 != 0 || (q.src_ld * 2) % 16 != 0) return false;
+    if ((long)q.N * q.Hd * q.Wd >= (1L << 31)) return false;
+    tiles += (((long)q.N * q.Hd * q.Wd + 255) / 256) * (wide ? tn : 1);
+  }
+  return tiles >= 256;
+}
+
+int dy_conv_v5_launch_classes(const dy_conv_desc* c, int ncls, void* stream) { return v5_launch(&c[0], 0, stream, c, ncls); }
+
+static int v5_launch(const dy_conv_desc* d, int mode, void* stream, const dy_conv_desc* classes, int ncls) {
   v5::P p;
   p.src = (const char*)d->src; p.w = (const char*)d->w; p.dst = (char*)d->dst;
   p.src_ld = d->src_ld; p.dst_ld = d->dst_ld;
@@ -659,6 +716,23 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   const int bn = d->Cd <= 64 ? 64 : 128;
   p.tiles_n = dy_cdiv(d->Cd, bn);
   p.nblk = dy_cdiv(p.M, v5::BM) * p.tiles_n;
+  p.ncls = 0;
+  if (ncls > 1) {
+    DY_CHECK(ncls <= 4 && mode == 0, "conv_v5: at most 4 forward-style classes");
+    p.ncls = ncls;
+    int slot = 0;
+    for (int c = 0; c < ncls; ++c) {
+      const dy_conv_desc& q = classes[c];
+      DyParityCls& k = p.cls[c];
+      k.dst = (char*)q.dst; k.M = (long)q.N * q.Hd * q.Wd; k.Hd = q.Hd; k.Wd = q.Wd; k.KH = q.KH; k.KW = q.KW; k.pad = q.pad;
+      k.kh0 = q.kh0; k.kw0 = q.kw0; k.Ktot = q.KH * q.KW * q.Cs;
+      const int tiles = (int)dy_cdiv(k.M, (long)v5::BM) * p.tiles_n;
+      k.blk0 = slot;
+      k._r = dy_cdiv(tiles, 8);
+      slot += k._r;
+    }
+    p.nblk = 8 * slot;
+  }
   constexpr int RING128 = v5::NSTAGE * (v5::A_BYTES + 128 * 64), EPI128 = dy_epi::row_image_bytes<v5::BM, 128>();
   constexpr int RING64 = 4 * (v5::A_BYTES + 64 * 64), EPI64 = dy_epi::row_image_bytes<v5::BM, 64>();
   constexpr int SH128 = RING128 > EPI128 ? RING128 : EPI128, SH64 = RING64 > EPI64 ? RING64 : EPI64;
@@ -674,7 +748,7 @@ int dy_conv_v5_launch(const dy_conv_desc* d, int mode, void* stream) {
   static_assert(2 * SH128 <= 160 * 1024 && 2 * SH64 <= 160 * 1024 && 2 * SB128 <= 160 * 1024 && 2 * SB64 <= 160 * 1024, "two blocks per CU");
   // 3x3 / stride 1 / pad 1 on an unchanged pixel grid: the band kernel
   static const bool no_band = dy_env("DY_NO_CONV_BAND") != nullptr;
-  const bool band = !no_band && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->KHf <= 0 && d->Hs == d->Hd &&
+  const bool band = ncls <= 1 && !no_band && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->KHf <= 0 && d->Hs == d->Hd &&
                     d->Ws == d->Wd && d->Ws >= 16;
   static bool configured = false;
   if (!configured) {

@@ -100,7 +100,11 @@ ROUTED = [
     ((31, 192, 232, 41, 43, 3, 1, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # ragged pixels / channels
     ((13, 512, 256, 80, 80, 1, 1, 0), ("v4::conv_kernel", "v5::conv_kernel<128>", "wg4::wgrad_kernel")),        # 1x1: K = 512 / K = 256
     ((13, 128, 256, 80, 80, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),                                    # K = 128: two co-resident blocks
-    ((20, 256, 512, 80, 80, 3, 2, 1), ("v4::conv_kernel", None, "wg4::wgrad_kernel")),                         # stride 2 (dgrad: parity classes)
+    ((20, 256, 512, 80, 80, 3, 2, 1), ("v4::conv_kernel", "v4::conv_kernel", "wg4::wgrad_kernel")),            # stride 2 (dgrad: the four parity classes in ONE conv_v4 launch)
+    ((9, 256, 320, 81, 79, 3, 2, 1), (None, "v4::conv_kernel", None)),                                          # ... odd extents: classes of different grid sizes, ragged channels
+    ((40, 512, 512, 40, 40, 3, 2, 1), (None, "v4::conv_kernel", None)),                                         # ... two channel tiles; 100 row tiles per class
+    ((10, 128, 256, 161, 159, 3, 2, 1), (None, "v5::conv_kernel<128>", None)),                                  # ... on conv_v5 (128 gradient channels), odd extents
+    ((5, 64, 128, 320, 320, 3, 2, 1), (None, "v5::conv_kernel<64>", None)),                                     # ... 64 gradient channels
     ((24, 128, 128, 80, 80, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", "wg3::wgrad_kernel<128>")), # 3x3 s1 p1: activation band; band weight gradient
     ((128, 128, 128, 33, 16, 3, 1, 1), ("v5::band_kernel<128>", "v5::band_kernel<128>", None)),                 # narrowest image the band takes
     ((120, 64, 64, 33, 17, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", None)),                     # ragged: a tile spans 15 image rows

@@ -81,6 +81,8 @@ int main(int argc, char** argv) {
     dy_conv_desc g = {};
     g.src = dy; g.src_ld = s.Cout; g.N = s.B; g.Hs = Ho; g.Ws = Wo; g.Cs = s.Cout; g.w = dwt; g.dst = dz; g.dst_ld = s.Cin;
     g.Hd = s.H; g.Wd = s.W; g.Cd = s.Cin; g.KH = g.KW = s.k; g.stride = s.s; g.pad = s.p; g.dil = 1; g.dtype = DY_BF16;
+    if (getenv("CB_ACC")) g.accumulate = 1;                 // the data gradient as the graph issues it for a fan-out: dx += ...
+    if (getenv("CB_ADD")) { g.add_src = dx; g.add_src_ld = s.Cin; }        // ... or dx = dgrad + another gradient view
     const double flops = 2.0 * s.B * Ho * Wo * (double)s.Cout * s.k * s.k * s.Cin;
     float ms[3];
     for (int which = 0; which < 3; ++which) {
