@@ -71,6 +71,7 @@ PIPELINED = [(2, 64, 128, 40, 40, 3, 1, 1), (3, 128, 64, 32, 32, 3, 2, 1), (2, 6
              (4, 128, 96, 40, 40, 3, 1, 3, 3), (9, 64, 64, 128, 128, 3, 1, 1), (2, 384, 256, 48, 48, 1, 1, 0),
              (4, 32, 32, 40, 40, 3, 1, 1), (4, 16, 16, 48, 40, 3, 1, 1), (4, 48, 32, 40, 40, 1, 1, 0),   # narrow layers, M >= 2048
              (4, 16, 32, 41, 39, 3, 2, 1), (2, 8, 16, 64, 64, 3, 2, 1), (4, 24, 40, 33, 35, 3, 1, 1),
+             (2, 3, 64, 64, 96, 3, 2, 1), (1, 3, 64, 33, 47, 3, 2, 1), (2, 8, 64, 40, 42, 3, 2, 1),     # the L stem: MFMA data gradient (planar / NHWC8)
              (4, 32, 64, 40, 40, 3, 1, 1), (4, 48, 96, 40, 40, 1, 1, 0), (4, 16, 72, 41, 40, 3, 2, 1),   # narrow source, wide destination
              (2, 128, 272, 48, 48, 3, 1, 1), (4, 64, 512, 33, 31, 3, 2, 1),   # >= 256 output channels: 256x256 wgrad / conv tiles
              (6, 60, 62, 150, 147, 3, 1, 1),   # band weight gradient (64-channel 3x3, long pixel loop), ragged width / channels
@@ -174,3 +175,35 @@ def test_thin_kernel_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv_kernels.py"), "-q", "-x", "-k",
                         "thin_route_all_shapes", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype,B,Cout,H,W", [(torch.bfloat16, 2, 64, 64, 96), (torch.bfloat16, 3, 16, 33, 47), (torch.float16, 2, 32, 40, 41),
+                                             (torch.bfloat16, 1, 64, 641, 17)], ids=lambda v: str(v).replace("torch.", ""))
+def test_stem_forward_kernel(dtype, B, Cout, H, W):
+    """The direct MFMA kernel of the network stem (Conv(3, c, 3, 2) on the zero-padded NHWC8 image, raw output + BatchNorm sums -- the
+    training forward of yolov8*.yaml layer 1): output against F.conv2d on the rounded operands, per-channel sum / sum of squares of the
+    f32 accumulators against the same reference, odd extents (padding on all four borders, a ragged last 16-pixel group)."""
+    import ctypes as C
+    from dedark_yolo_amd import _C, ops
+    from dedark_yolo_amd.ops import ptr, stream
+    torch.manual_seed(H * 7 + W)
+    x = torch.randn(B, 3, H, W, device="cuda")
+    w = torch.randn(Cout, 3, 3, 3, device="cuda") * 0.2
+    xn = ops.as_nhwc(x, dtype)                                   # [B, 8 (3 used), H, W] view of an NHWC8 buffer
+    assert ops.padded_channels(xn) == 8
+    wp = ops._pack(w, Cout, 8, False, dtype)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = ops.empty_nhwc(B, Cout, Ho, Wo, dtype, x.device)
+    stats = torch.zeros(_C.STATS_REPLICAS * 2 * Cout, dtype=torch.float64, device="cuda")
+    d = ops._conv_desc(xn, wp, y, B, H, W, 8, Ho, Wo, Cout, 3, 3, 2, 1, 1, None, None, 0, stats, False, dtype)
+    _C.lib().dy_clear_last_kernel()
+    _C.call("dy_conv2d_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    assert _C.lib().dy_last_kernel().decode() == "stem_fwd_kernel"
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), None, 2, 1)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert _err(y.float(), ref) < tol
+    t = stats.view(_C.STATS_REPLICAS, 2, Cout).sum(0)
+    s1, s2 = ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))
+    assert float((t[0] - s1).abs().max()) <= 1e-4 * float(ref.abs().double().sum((0, 2, 3)).max())
+    assert float((t[1] - s2).abs().max()) <= 1e-4 * float(s2.max())

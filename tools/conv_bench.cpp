@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
       {"s4 3x3 256->256 @20", B, 256, 256, 20, 20, 3, 1, 1},   {"s4 3x3 128->128 @40", B, 128, 128, 40, 40, 3, 1, 1},
       {"1x1 128->128 @160", B, 128, 128, 160, 160, 1, 1, 0},   {"3x3s2 128->256 @160", B, 128, 256, 160, 160, 3, 2, 1},
       {"3x3s2 512->512 @40", B, 512, 512, 40, 40, 3, 2, 1},    {"3x3s2 256->256 @80", B, 256, 256, 80, 80, 3, 2, 1},
+      {"stem 3x3s2 8->64 @640", B, 8, 64, 640, 640, 3, 2, 1},
   };
   if (argc > 3 && argv[3][0] == 'n') {       // YOLOv8-n layers with few output pixels (B = 32: 12,800 / 51,200 rows)
     shapes = {
