@@ -55,6 +55,9 @@ bool dy_wgrad_v3_eligible(int dtype, int Cin_pad, int Cout_pad, int KH, int KW, 
 int dy_wgrad_v3_launch(const void* x, long x_ld, int N, int Hi, int Wi, int Cin_pad, const void* dz, long dz_ld, int Cout_pad, int Cout,
                        int Cin, float* scratch, long scratch_elems, float* g_oihw, int dtype, void* stream);
 // direct stem kernels (conv_small.hip)
+bool dy_conv_px_eligible(const dy_conv_desc* d);
+bool dy_conv_px_has_shape(const dy_conv_desc* d);
+int dy_conv_px_launch(const dy_conv_desc* d, void* stream);
 bool dy_conv_stem_fwd_eligible(const dy_conv_desc* d);
 int dy_conv_stem_fwd_launch(const dy_conv_desc* d, void* stream);
 bool dy_conv_small_dgrad_eligible(const dy_conv_desc* d);
@@ -995,6 +998,7 @@ extern "C" int dy_conv2d_fwd(const dy_conv_desc* d, void* stream) {
   DY_CHECK(ho == d->Hd && wo == d->Wd, "dy_conv2d_fwd: dst %dx%d does not match conv output %dx%d", d->Hd, d->Wd, ho, wo);
   if (dy_dense_fwd_eligible(d)) return dy_dense_fwd_launch(d, stream);
   if (dy_conv_stem_fwd_eligible(d)) return dy_conv_stem_fwd_launch(d, stream);
+  if (dy_conv_px_eligible(d) && dy_conv_px_has_shape(d) && !d->accumulate && !d->add_src) return dy_conv_px_launch(d, stream);
   if (dy_conv_v4_eligible(d, 0)) return dy_conv_v4_launch(d, 0, stream);
   if (dy_conv_v5_eligible(d, 0)) return dy_conv_v5_launch(d, 0, stream);
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 0, stream);
@@ -1095,7 +1099,8 @@ static int dgrad_dispatch(const dy_conv_desc* d, void* stream, bool* added) {
       return 0;
     }
   }
-  // the two large-tile kernels add the optional `add_src` view in their epilogue
+  // the pixel-streaming 1x1 kernel and the two large-tile kernels add the optional `add_src` view in their epilogue
+  if (dy_conv_px_eligible(d) && dy_conv_px_has_shape(d)) { *added = true; return dy_conv_px_launch(d, stream); }
   if (dy_conv_v4_eligible(d, 1)) { *added = true; return dy_conv_v4_launch(d, 1, stream); }
   if (dy_conv_v5_eligible(d, 1)) { *added = true; return dy_conv_v5_launch(d, 1, stream); }
   if (dy_conv_v3_eligible(d)) return dy_conv_v3_launch(d, 1, stream);

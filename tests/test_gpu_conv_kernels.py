@@ -207,3 +207,47 @@ def test_stem_forward_kernel(dtype, B, Cout, H, W):
     s1, s2 = ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))
     assert float((t[0] - s1).abs().max()) <= 1e-4 * float(ref.abs().double().sum((0, 2, 3)).max())
     assert float((t[1] - s2).abs().max()) <= 1e-4 * float(s2.max())
+
+
+@pytest.mark.parametrize("dtype,K,N,mode", [(torch.bfloat16, 128, 128, "stats"), (torch.bfloat16, 320, 128, "stats"), (torch.float16, 64, 64, "stats"),
+                                          (torch.bfloat16, 128, 320, "plain"), (torch.bfloat16, 128, 320, "acc"), (torch.float16, 128, 128, "add"),
+                                          (torch.bfloat16, 64, 128, "add")], ids=lambda v: str(v).replace("torch.", ""))
+def test_px1x1_kernel(dtype, K, N, mode):
+    """The pixel-streaming 1x1 kernel (weights resident in LDS, pixel operands straight from memory; the short-K layers of the 160x160
+    stage and their data gradients): y[m][n] = sum_k x[m][k] w[n][k] against torch on the rounded operands, with BatchNorm sums (forward),
+    accumulating into the destination and with an addend view (data gradients), on a pixel count that is no multiple of 32."""
+    import ctypes as C
+    from dedark_yolo_amd import _C, ops
+    from dedark_yolo_amd.ops import ptr, stream
+    torch.manual_seed(K + N)
+    B, H, W = 7, 197, 191                                       # 263,389 pixels
+    x = torch.randn(B, K, H, W, device="cuda") * 0.5
+    w = torch.randn(N, K, 1, 1, device="cuda") * (1.0 / K ** 0.5)
+    xn = ops.as_nhwc(x, dtype)
+    wp = ops._pack(w, N, K, False, dtype)
+    y = ops.empty_nhwc(B, N, H, W, dtype, x.device)
+    old = torch.randn(B, N, H, W, device="cuda")
+    addend = ops.as_nhwc(torch.randn(B, N, H, W, device="cuda"), dtype)
+    if mode == "acc":
+        y.copy_(old.to(dtype))
+    stats = torch.zeros(_C.STATS_REPLICAS * 2 * N, dtype=torch.float64, device="cuda") if mode == "stats" else None
+    d = ops._conv_desc(xn, wp, y, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, None, None, 0, stats, mode == "acc", dtype)
+    if mode == "add":
+        d.add_src, d.add_src_ld = addend.data_ptr(), ops.ld_of(addend)
+    _C.lib().dy_clear_last_kernel()
+    _C.call("dy_conv2d_fwd" if mode == "stats" else "dy_conv2d_dgrad", C.byref(d), stream())
+    torch.cuda.synchronize()
+    assert _C.lib().dy_last_kernel().decode() == "px1x1_kernel"
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float())
+    raw = ref
+    if mode == "acc":
+        ref = ref + old.to(dtype).float()
+    if mode == "add":
+        ref = ref + addend.float()
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert _err(y.float(), ref) < tol
+    if mode == "stats":
+        t = stats.view(_C.STATS_REPLICAS, 2, N).sum(0)
+        s1, s2 = raw.double().sum((0, 2, 3)), (raw.double() ** 2).sum((0, 2, 3))
+        assert float((t[0] - s1).abs().max()) <= 1e-4 * float(raw.abs().double().sum((0, 2, 3)).max())
+        assert float((t[1] - s2).abs().max()) <= 1e-4 * float(s2.max())

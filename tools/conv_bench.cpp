@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
       {"1x1 128->128 @160", B, 128, 128, 160, 160, 1, 1, 0},   {"3x3s2 128->256 @160", B, 128, 256, 160, 160, 3, 2, 1},
       {"3x3s2 512->512 @40", B, 512, 512, 40, 40, 3, 2, 1},    {"3x3s2 256->256 @80", B, 256, 256, 80, 80, 3, 2, 1},
       {"stem 3x3s2 8->64 @640", B, 8, 64, 640, 640, 3, 2, 1},
+      {"1x1 64->64 @160", B, 64, 64, 160, 160, 1, 1, 0},
   };
   if (argc > 3 && argv[3][0] == 'n') {       // YOLOv8-n layers with few output pixels (B = 32: 12,800 / 51,200 rows)
     shapes = {
