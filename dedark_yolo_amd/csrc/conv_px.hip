@@ -27,6 +27,8 @@ struct P {
   long y_ld;
   long M;
   int K, N;
+  int chunks;                    // > 1: the output channels are cut into chunks of 32 * NS; block b works on chunk b % chunks with its own
+                                 // weight rows in LDS and re-reads the pixels (wide-N data gradients: the re-reads are L2 / Infinity Cache hits)
   int accumulate;
   const char* add;
   long add_ld;
@@ -45,9 +47,13 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
   const T* x = reinterpret_cast<const T*>(p.x);
   T* y = reinterpret_cast<T*>(p.y);
   const T* add = reinterpret_cast<const T*>(p.add);
-  for (int i = tid; i < p.N * KB * 4; i += NT) {           // weights -> LDS, 16-byte chunks
+  const int chunk = p.chunks > 1 ? (int)(blockIdx.x % p.chunks) : 0;
+  const int n0 = chunk * 32 * NS;                          // first output channel of this block
+  const int ns_here = (p.N - n0) / 32 < NS ? (p.N - n0) / 32 : NS;
+  const long blk = p.chunks > 1 ? blockIdx.x / p.chunks : blockIdx.x, nblk = p.chunks > 1 ? gridDim.x / p.chunks : gridDim.x;
+  for (int i = tid; i < 32 * ns_here * KB * 4; i += NT) {  // weights -> LDS, 16-byte chunks
     const int c = i / (KB * 4), ch = i - c * (KB * 4);
-    *reinterpret_cast<u32x4*>(smem + lds_row(c) * PITCH + ch * 16) = *reinterpret_cast<const u32x4*>(p.w + ((long)c * K + ch * 8) * 2);
+    *reinterpret_cast<u32x4*>(smem + lds_row(c) * PITCH + ch * 16) = *reinterpret_cast<const u32x4*>(p.w + ((long)(n0 + c) * K + ch * 8) * 2);
   }
   __syncthreads();
   const int a_base = col * PITCH + 16 * g;                 // + (32 s + 16 u) * PITCH + 64 kb
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
       for (int e = 0; e < 8; ++e) s1[s][e] = s2[s][e] = 0.f;
   }
   const long groups = (p.M + 31) / 32;
-  for (long grp = (long)blockIdx.x * (NT / 64) + wave; grp < groups; grp += (long)gridDim.x * (NT / 64)) {
+  for (long grp = blk * (NT / 64) + wave; grp < groups; grp += nblk * (NT / 64)) {
     u32x4 xf[2][KB];
     long m[2];
     bool live[2];
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
 #pragma unroll UNR
     for (int s = 0; s < NS; ++s) {
       __builtin_amdgcn_sched_barrier(0);
+      if (s >= ns_here) break;                             // (block-uniform: the last chunk of a wide layer may be shorter)
       f32x4 acc[2][2];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
           }
         }
         if (live[q]) {
-          T* o = y + m[q] * p.y_ld + 32 * s + 8 * g;
+          T* o = y + m[q] * p.y_ld + n0 + 32 * s + 8 * g;
           if (p.accumulate || add) {
             float t[8];
             if (p.accumulate) {
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
               for (int e = 0; e < 8; ++e) v[e] += t[e];
             }
             if (add) {
-              ldvec<T>(add + m[q] * p.add_ld + 32 * s + 8 * g, t);
+              ldvec<T>(add + m[q] * p.add_ld + n0 + 32 * s + 8 * g, t);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += t[e];
             }
@@ -153,15 +160,21 @@ __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
 }  // namespace px
 
 // Raw-output 1x1 / stride-1 layers on an unchanged pixel grid, K in {64, 128, 320}, N a multiple of 32, the weight image within LDS;
-// BatchNorm sums only up to 128 output channels (they live in registers); long pixel ranges (the layers of the 160x160 / 320x320 stages).
+// BatchNorm sums only up to 128 output channels (they live in registers); long pixel ranges (the layers of the 160x160 / 320x320 stages);
+// K = 256 with up to 1024 output channels in chunks of 256 (the wide 1x1 data gradients of the 80x80 stage; no sums).
 bool dy_conv_px_eligible(const dy_conv_desc* d) {
   static const bool off = dy_env("DY_NO_CONV_PX") != nullptr;
   if (off || (d->dtype != DY_BF16 && d->dtype != DY_F16)) return false;
   if (!(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->KHf == 0 && d->dst_row_stride == 0 && d->dst && !d->dst_planar &&
         d->Hs == d->Hd && d->Ws == d->Wd && !d->scale && !d->shift && d->act == DY_ACT_NONE))
     return false;
-  if (!(d->Cs == 64 || d->Cs == 128 || d->Cs == 320) || d->Cd % 32 != 0 || d->Cd < 64 || d->Cd > 320) return false;
-  if ((long)d->Cd * (2 * d->Cs + 16) > 150 * 1024) return false;
+  if (d->Cd % 32 != 0 || d->Cd < 64) return false;
+  if (d->Cs == 256) {                                  // wide data gradients of the 80x80 stage: output channels in chunks of 256
+    if (d->stats || d->Cd > 1024) return false;
+  } else {
+    if (!(d->Cs == 64 || d->Cs == 128 || d->Cs == 320) || d->Cd > 320) return false;
+    if ((long)d->Cd * (2 * d->Cs + 16) > 150 * 1024) return false;
+  }
   if (d->stats && (d->Cd > 128 || d->accumulate || d->add_src)) return false;
   if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0 || ((uintptr_t)d->src) % 16 != 0) return false;
   if (d->add_src && ((d->add_src_ld * 2) % 16 != 0 || ((uintptr_t)d->add_src) % 16 != 0)) return false;
@@ -190,12 +203,15 @@ int dy_conv_px_launch(const dy_conv_desc* d, void* stream) {
   p.x = (const char*)d->src; p.x_ld = d->src_ld; p.w = (const char*)d->w; p.y = (char*)d->dst; p.y_ld = d->dst_ld;
   p.M = (long)d->N * d->Hd * d->Wd; p.K = d->Cs; p.N = d->Cd; p.accumulate = d->accumulate;
   p.add = (const char*)d->add_src; p.add_ld = d->add_src_ld; p.stats = d->stats;
-  const size_t w_bytes = (size_t)d->Cd * (2 * d->Cs + 16), red_bytes = (size_t)(px::NT / 64) * d->Cd * 8;
+  const int chunk_n = d->Cs == 256 ? 256 : d->Cd;          // output channels per block
+  p.chunks = (d->Cd + chunk_n - 1) / chunk_n;
+  const int rows = d->Cd < chunk_n ? d->Cd : chunk_n;
+  const size_t w_bytes = (size_t)rows * (2 * d->Cs + 16), red_bytes = (size_t)(px::NT / 64) * d->Cd * 8;
   const size_t shm = w_bytes > red_bytes ? w_bytes : red_bytes;
-  const int per_cu = 1;
   const long groups = (p.M + 31) / 32;
-  long blocks = 256L * per_cu;
+  long blocks = 256;                                       // one block (8 waves) per CU
   if (blocks * (px::NT / 64) > groups) blocks = (groups + px::NT / 64 - 1) / (px::NT / 64);
+  if (p.chunks > 1) blocks = (256 / p.chunks) * p.chunks;  // a whole number of blocks per chunk
   hipStream_t st = (hipStream_t)stream;
   const bool stats = d->stats != nullptr;
   const bool f16 = d->dtype == DY_F16;
@@ -209,6 +225,7 @@ int dy_conv_px_launch(const dy_conv_desc* d, void* stream) {
   else if (kb == 10 && ns == 4) PX(10, 4);
   else if (kb == 4 && ns == 10) PX(4, 10);
   else if (kb == 2 && ns == 4) PX(2, 4);
+  else if (kb == 8) PX(8, 8);                              // chunks of 256 channels (the last one may be shorter)
 #undef PX
   DY_CHECK(rc != 4, "conv_px: no instantiation for K=%d N=%d", d->Cs, d->Cd);
   if (rc) return rc;
@@ -218,5 +235,6 @@ int dy_conv_px_launch(const dy_conv_desc* d, void* stream) {
 
 bool dy_conv_px_has_shape(const dy_conv_desc* d) {
   const int kb = d->Cs / 32, ns = d->Cd / 32;
-  return (kb == 2 && ns == 2) || (kb == 4 && ns == 2) || (kb == 4 && ns == 4) || (kb == 10 && ns == 4) || (kb == 4 && ns == 10) || (kb == 2 && ns == 4);
+  return (kb == 2 && ns == 2) || (kb == 4 && ns == 2) || (kb == 4 && ns == 4) || (kb == 10 && ns == 4) || (kb == 4 && ns == 10) || (kb == 2 && ns == 4) ||
+         kb == 8;
 }

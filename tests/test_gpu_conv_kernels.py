@@ -211,7 +211,10 @@ def test_stem_forward_kernel(dtype, B, Cout, H, W):
 
 @pytest.mark.parametrize("dtype,K,N,mode", [(torch.bfloat16, 128, 128, "stats"), (torch.bfloat16, 320, 128, "stats"), (torch.float16, 64, 64, "stats"),
                                           (torch.bfloat16, 128, 320, "plain"), (torch.bfloat16, 128, 320, "acc"), (torch.float16, 128, 128, "add"),
-                                          (torch.bfloat16, 64, 128, "add")], ids=lambda v: str(v).replace("torch.", ""))
+                                          (torch.bfloat16, 64, 128, "add"),
+                                          # K = 256: output channels in chunks of 256 (the wide data gradients of the 80x80 stage; 640 = 2.5 chunks)
+                                          (torch.bfloat16, 256, 1024, "plain"), (torch.bfloat16, 256, 640, "acc"), (torch.float16, 256, 256, "add")],
+                         ids=lambda v: str(v).replace("torch.", ""))
 def test_px1x1_kernel(dtype, K, N, mode):
     """The pixel-streaming 1x1 kernel (weights resident in LDS, pixel operands straight from memory; the short-K layers of the 160x160
     stage and their data gradients): y[m][n] = sum_k x[m][k] w[n][k] against torch on the rounded operands, with BatchNorm sums (forward),
