@@ -18,6 +18,11 @@
 namespace px {
 
 constexpr int NT = 512;
+// weight rows in LDS are padded by TWO 16-byte slots: lane (col, g) of a ds_read_b128 then reads slot 2 col + g (K = 128, 256) or
+// 10 col + g (K = 64, 320) of the 16-slot bank row, and each of the instruction's 16-lane groups ({cols 0-3, 12-15} of k-chunk g with
+// {cols 4-11} of chunk g ^ 1) covers all 16 slots; with one slot of padding (slot col + g) every group had one pair on the same slot
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 on every px instance, profiles/r03_lds_conflicts.txt)
+constexpr int ROW_PAD = 32;
 
 struct P {
   const char* x;
@@ -41,7 +46,7 @@ __device__ inline int lds_row(int c) { return (c & ~31) + 16 * ((c >> 2) & 1) + 
 template <int KB, int NS, typename T, bool STATS>
 __global__ __launch_bounds__(NT) void px1x1_kernel(const P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int K = 32 * KB, PITCH = 2 * K + 16, UNR = NS;
+  constexpr int K = 32 * KB, PITCH = 2 * K + px::ROW_PAD, UNR = NS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const T* x = reinterpret_cast<const T*>(p.x);
@@ -173,7 +178,7 @@ bool dy_conv_px_eligible(const dy_conv_desc* d) {
     if (d->stats || d->Cd > 1024) return false;
   } else {
     if (!(d->Cs == 64 || d->Cs == 128 || d->Cs == 320) || d->Cd > 320) return false;
-    if ((long)d->Cd * (2 * d->Cs + 16) > 150 * 1024) return false;
+    if ((long)d->Cd * (2 * d->Cs + px::ROW_PAD) > 150 * 1024) return false;
   }
   if (d->stats && (d->Cd > 128 || d->accumulate || d->add_src)) return false;
   if ((d->src_ld * 2) % 16 != 0 || (d->dst_ld * 2) % 16 != 0 || ((uintptr_t)d->dst) % 16 != 0 || ((uintptr_t)d->src) % 16 != 0) return false;
@@ -206,7 +211,7 @@ int dy_conv_px_launch(const dy_conv_desc* d, void* stream) {
   const int chunk_n = d->Cs == 256 ? 256 : d->Cd;          // output channels per block
   p.chunks = (d->Cd + chunk_n - 1) / chunk_n;
   const int rows = d->Cd < chunk_n ? d->Cd : chunk_n;
-  const size_t w_bytes = (size_t)rows * (2 * d->Cs + 16), red_bytes = (size_t)(px::NT / 64) * d->Cd * 8;
+  const size_t w_bytes = (size_t)rows * (2 * d->Cs + px::ROW_PAD), red_bytes = (size_t)(px::NT / 64) * d->Cd * 8;
   const size_t shm = w_bytes > red_bytes ? w_bytes : red_bytes;
   const long groups = (p.M + 31) / 32;
   long blocks = 256;                                       // one block (8 waves) per CU

@@ -443,8 +443,12 @@ __global__ __launch_bounds__(256, (BN == 64 && NBAND_ == 2) ? 3 : 2) void band_k
 
   // ---- DMA bookkeeping: wave instruction idx = wave + 4j fills band rows 16*idx .. +15 (j < 4) / weight rows (j < B_LD); the 17th
   // band block (rows 256 .. 271, of which 256 and 257 are read) is filled by all four waves, 16 lanes each
+  // (band rows are read at three alignments -- row r + 0 / 1 / 2 for the three column taps -- so the band kernel keys the slot swizzle
+  // on bit 2 of the row, chunk c of row r in slot c ^ ((r & 4) ? 2 : 0): the four rows r, r+4, r+8, r+12 of a ds_read_b128 lane group that
+  // share a quarter of the 256-byte bank row then sit in four different slots for EVERY starting row, where conv_kernel's key on bit 3
+  // is conflict-free only for 16-aligned reads: 2-way on the shifted taps, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33 / 0.23)
   const int lrow = lane >> 2, slot = lane & 3;
-  const int chunk = slot ^ ((lane & 32) ? 3 : 0);
+  const int chunk = slot ^ ((lane & 16) ? 2 : 0);
   const bool tail_lane = (lane >> 4) == wave;
   unsigned a_off[5], b_off[B_LD];
 #pragma unroll
@@ -494,9 +498,9 @@ __global__ __launch_bounds__(256, (BN == 64 && NBAND_ == 2) ? 3 : 2) void band_k
 #pragma unroll
   for (int tw = 0; tw < 3; ++tw) {
     const int brow = r0 + 1 + p.dw0 + p.dws * tw;
-    a_rd[tw] = brow * 64 + ((fq ^ ((brow & 8) ? 3 : 0)) * 16);             // + 1024 * m-block
+    a_rd[tw] = brow * 64 + ((fq ^ ((brow & 4) ? 2 : 0)) * 16);             // + 1024 * m-block
   }
-  const int b_rd = (64 * wn + fr) * 64 + ((fq ^ ((fr & 8) ? 3 : 0)) * 16); // + 1024 * n-block
+  const int b_rd = (64 * wn + fr) * 64 + ((fq ^ ((fr & 4) ? 2 : 0)) * 16); // + 1024 * n-block
   // padding masks: bit 8*tw + i of tm[th] = tap (th, tw) of this lane's pixel of m-block i lies inside the image
   unsigned tm[3] = {0u, 0u, 0u};
   {

@@ -18,6 +18,12 @@
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
+// diagnostics only (tools/gpu/wg3_ablate.sh builds variant libraries with -DWG3_ABLATE=n; results are wrong, only the time matters):
+// 1 = DMA + one barrier per row only, 2 = DMA + MFMAs on register constants (no fragment reads), 3 = the bare MFMA loop (no DMA either)
+#ifndef WG3_ABLATE
+#define WG3_ABLATE 0
+#endif
+
 namespace wg3 {
 
 constexpr int CO = 64;                    // output channels per block
@@ -45,6 +51,18 @@ struct P {
   float* part;     // [co slices][blocks][9*CI][64]
 };
 
+// Bank swizzle of the row buffers.  A 32-lane half of ds_read_b64_tr_b16 reads 4 consecutive pixels x 32 channels (64 bytes per pixel)
+// and the LDS bank row is 256 bytes: with plain [pixel][channel] rows the four pixels sit a multiple of 256 bytes apart (128 channels:
+// 4-way conflict) or two of them do (64 channels: 2-way) -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.69 on 128->128 at 80x80,
+// exactly 6 x reads at 4x + 4 dz reads at 2x per slice, and the LDS array, not the MFMA pipe, set the pace.  So the 64-byte quarter q of
+// slot pixel P is stored at quarter q ^ key(P), with key chosen so that 4 consecutive pixels land in 4 different quarters of the bank
+// row: 128 channels (one pixel per bank row) key = P & 3; 64 channels (two pixels per bank row) key = (P >> 1) & 1.  The DMA is
+// lane-linear in LDS, so the permutation is applied to the SOURCE chunk a lane fetches.
+template <int C>
+__device__ inline int swizzle_key(int P) {
+  return C == 128 ? (P & 3) : ((P >> 1) & 1);
+}
+
 // one image row (or one column strip of it) -> one LDS row buffer; `shift` = slot index of image column col0 (2 for x, 1 for dz); rows
 // outside the image and image columns outside [lo, hi) come from the zero page.  x rows are loaded with one halo column on each side of
 // the strip (real neighbours, zeros only at the image border); dz rows with exactly the strip's columns, so that strips partition the sum.
@@ -57,10 +75,17 @@ __device__ inline void load_row(const char* src, long ld, int c0, int n, int h, 
   constexpr int CPP = C / 8;                            // 16-byte chunks per pixel
   const int ninstr = slots / PPI;
   const bool rowok = h >= 0 && h < H;
-  const int pl = lane / CPP, chunk = lane % CPP;
+  const int pl = lane / CPP;
+  const int chunk = (lane % CPP) ^ swizzle_key<C>(pl) * 4;         // PPI is a multiple of 4: the key of slot PPI*i + pl is that of pl
+  // wave-uniform row base (scalar registers) + one 32-bit offset per lane: `wave` is uniform (readfirstlane), so the instruction loop, the
+  // LDS destination (M0) and the 64-bit row arithmetic stay on the scalar unit
+  const int ldb = (int)ld * 2;
+  const char* row = src + ((((long)n * H + h) * W + col0) * ld + c0) * 2;
+  const int voff = (pl - shift) * ldb + chunk * 16;
+  const int wl = col0 + pl - shift;
   for (int i = wave; i < ninstr; i += NW) {
-    const int w = col0 + PPI * i + pl - shift;
-    const char* g = (rowok && w >= lo && w < hi) ? src + ((((long)n * H + h) * W + w) * ld + c0 + chunk * 8) * 2 : zero;
+    const int w = wl + PPI * i;
+    const char* g = (rowok && w >= lo && w < hi) ? row + (long)(PPI * i) * ldb + voff : zero;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + i * 1024), 16, 0, 0);
   }
 }
@@ -72,7 +97,8 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   constexpr int KT = 9 * CT;                            // k' tiles of 32
   constexpr int NW = KT / 3;                            // waves (3 k' tiles x 2 co tiles each)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int XB = p.XW * PXB, ZB = p.PW * ZPB;           // bytes per x / dz row buffer
   const int co0 = blockIdx.y * CO;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
@@ -102,9 +128,11 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
   for (int i = 0; i < 3; ++i) {
     const int kt = 3 * wave + i, tap = kt / CT, ct = kt - tap * CT;
     a_kh[i] = tap / 3;
-    a_off[i] = (tap - 3 * a_kh[i]) * PXB + ct * 64 + lane_x;        // x slot index = px + kw
+    const int kw = tap - 3 * a_kh[i];
+    a_off[i] = kw * PXB + (ct ^ swizzle_key<CI>(kw + tq)) * 64 + lane_x;        // x slot index = px + kw (px = 16 s + 8 hh + tq, + 4)
   }
-  const int b_off[2] = {lane_z, 64 + lane_z};
+  const int kz = swizzle_key<CO>(tq);
+  const int b_off[2] = {kz * 64 + lane_z, (1 ^ kz) * 64 + lane_z};
 
   // slot of image row r in the x ring: (r + 1) & 3
   load_row<CI, NW>(p.x, p.x_ld, 0, n, h0 - 1, p.H, p.W, xring + ((h0 + 0) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
@@ -116,7 +144,7 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
 
   const int nslices = p.PW >> 4;
   for (int h = h0; h < h1; ++h) {
-    if (h + 1 < h1) {                                    // prefetch what the next row needs
+    if (h + 1 < h1 && WG3_ABLATE != 3) {                 // prefetch what the next row needs
       load_row<CI, NW>(p.x, p.x_ld, 0, n, h + 2, p.H, p.W, xring + ((h + 3) & 3) * XB, p.XW, 2, wave, lane, zero, col0, xlo, xhi);
       load_row<CO, NW>(p.dz, p.dz_ld, co0, n, h + 1, p.H, p.W, zring + ((h + 1) & 1) * ZB, p.PW, 1, wave, lane, zero, col0, col0, zhi);
     }
@@ -128,33 +156,65 @@ __global__ __launch_bounds__(CI * 6) void wgrad_kernel(P p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) xa[i] = lds0 + (unsigned)(((h + a_kh[i]) & 3) * XB + a_off[i]);       // x row h + kh - 1
     const unsigned zb = lds0 + (unsigned)(4 * XB + (h & 1) * ZB);
-    for (int s = 0; s < nslices; ++s) {
-      const unsigned so = s * 16 * PXB, sz = s * 16 * ZPB;
-      uint2 alo[3], ahi[3], blo[2], bhi[2];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[i]) : "v"(xa[i] + so) : "memory");
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(xa[i] + so), "n"(4 * PXB) : "memory");
+    // Two fragment sets; the 10 reads of slice s + 1 go into the gaps between the first MFMAs of slice s (4 + 4 + 2 behind MFMA 0, 1, 2:
+    // the last read has three MFMAs to land in), not as a burst in front of them -- the bare MFMA loop of this kernel takes 95 us on
+    // 128->128 at 80x80 (B = 64), the reads as a burst added 30 us on top of it (tools/gpu/wg3_ablate.sh).
+    uint2 alo[2][3], ahi[2][3], blo[2][2], bhi[2][2];
+    auto read_a = [&](int set, int s, int i) {
+      if (WG3_ABLATE >= 1) {
+        alo[set][i] = ahi[set][i] = uint2{0x3f803f80u + (unsigned)s, 0x3f803f80u + (unsigned)lane};
+        return;
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[j]) : "v"(zb + b_off[j] + sz) : "memory");
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[j]) : "v"(zb + b_off[j] + sz), "n"(4 * ZPB) : "memory");
+      const unsigned so = s * 16 * PXB;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[set][i]) : "v"(xa[i] + so) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[set][i]) : "v"(xa[i] + so), "n"(4 * PXB) : "memory");
+    };
+    auto read_b = [&](int set, int s, int j) {
+      if (WG3_ABLATE >= 1) {
+        blo[set][j] = bhi[set][j] = uint2{0x3f803f80u, 0x3f803f80u + (unsigned)s};
+        return;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned sz = s * 16 * ZPB;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[set][j]) : "v"(zb + b_off[j] + sz) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[set][j]) : "v"(zb + b_off[j] + sz), "n"(4 * ZPB) : "memory");
+    };
+    auto mfma = [&](int set, int i, int j) {
+      if (WG3_ABLATE == 1) return;
+      const u32x4 af = u32x4{alo[set][i].x, alo[set][i].y, ahi[set][i].x, ahi[set][i].y};
+      const u32x4 bf = u32x4{blo[set][j].x, blo[set][j].y, bhi[set][j].x, bhi[set][j].y};
+      acc[i][j] = mfma_32x32x16<T>(af, bf, acc[i][j]);
+    };
+    // one slice: the MFMAs of fragment set `cur`, slice sn read into the other set on the way (behind the last slice of the row the
+    // last slice once more, unused: one loop body for every slice)
+    auto slice = [&](int cur, int sn) {
+      if (WG3_ABLATE == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      u32x4 af[3], bf[2];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) af[i] = u32x4{alo[i].x, alo[i].y, ahi[i].x, ahi[i].y};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = u32x4{blo[j].x, blo[j].y, bhi[j].x, bhi[j].y};
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = mfma_32x32x16<T>(af[i], bf[j], acc[i][j]);
+      mfma(cur, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      read_a(cur ^ 1, sn, 0);
+      read_a(cur ^ 1, sn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(cur, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(cur ^ 1, sn, 0);
+      read_b(cur ^ 1, sn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(cur, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur ^ 1, sn, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(cur, 1, 1);
+      mfma(cur, 2, 0);
+      mfma(cur, 2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    read_a(0, 0, 0); read_a(0, 0, 1); read_a(0, 0, 2); read_b(0, 0, 0); read_b(0, 0, 1);
+    const int last = nslices - 1;
+    for (int s = 0; s < nslices; s += 2) {
+      slice(0, min(s + 1, last));
+      if (s + 1 < nslices) slice(1, min(s + 2, last));
     }
+    if (WG3_ABLATE == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unused reads behind the last slice
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
