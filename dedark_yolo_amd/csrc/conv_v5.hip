@@ -16,6 +16,7 @@
 // LDS rows are 64 bytes (32 bf16); 16-byte slot s of row r holds chunk s ^ (((r >> 2) & 2) ? 3 : 0): the four 16-lane groups of a
 // ds_read_b128 (16x16x32 operand: lane = row l&15, chunk l>>4) then hit 16 different slots of the 256-byte bank row.
 #include <stdlib.h>
+#include <type_traits>
 #include "dy_common.h"
 #include "conv_epilogue.h"
 #include "../../include/dedark_yolo.h"
@@ -344,13 +345,15 @@ __global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P pk) {
     issue(STAGE);
     advance();
     int cur = 0, fill = 2 * STAGE;
+    // (K-steps behind the last one are not issued: a dead DMA fetches nothing but takes the full round trip to retire, and the wait in
+    //  front of the epilogue -- which reuses the ring -- paid for it once per tile; the last step's wait covers everything in flight)
     for (int kt = 0; kt < p.nk; ++kt) {
-      if (DY_ABLATE_OF(p) & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if ((DY_ABLATE_OF(p) & 64) || kt + 1 >= p.nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + B_LD) : "memory");    // everything but the youngest stage: K-step kt has landed
       __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading K-step kt - 1
       __builtin_amdgcn_sched_barrier(0);
-      issue(fill);                                         // K-step kt + 2 into the stage K-step kt - 1 occupied
+      if (sk < p.nk) issue(fill);                          // K-step kt + 2 into the stage K-step kt - 1 occupied
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, walk);
       __builtin_amdgcn_sched_barrier(0);
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P pk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-step kt has landed (nothing younger is in flight)
       __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading K-step kt - 1
       __builtin_amdgcn_sched_barrier(0);
-      issue(cur ? 0 : STAGE);                              // K-step kt + 1 into the other stage
+      if (sk < p.nk) issue(cur ? 0 : STAGE);               // K-step kt + 1 into the other stage
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, walk);
       __builtin_amdgcn_sched_barrier(0);
@@ -385,9 +388,13 @@ __global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P pk) {
       __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading the previous pair
       __builtin_amdgcn_sched_barrier(0);
       const int nxt = cur ^ (2 * STAGE);
-      issue(nxt);                                          // next pair into the two stages the previous pair occupied
-      advance();
-      issue(nxt + STAGE);
+      if (sk < p.nk) {
+        issue(nxt);                                        // next pair into the two stages the previous pair occupied
+        advance();
+        issue(nxt + STAGE);                                // (the second step of an odd tail: zero fill, computed on)
+      } else {
+        advance();
+      }
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, walk);
       compute(cur + STAGE, nothing);
@@ -395,12 +402,14 @@ __global__ __launch_bounds__(256, SLIM ? 4 : 2) void conv_kernel(const P pk) {
       cur = nxt;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills of the steps beyond the last one have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (nothing is in flight any more unless the tile has a single K-step)
   __builtin_amdgcn_s_barrier();
   stamp(DY_ABLATE_OF(p), p.nblk, 2);
 
   epilogue<BN, T, MB>(p, acc, smem, tid, lane, wave, wm, wn, m0, n0, tile_m);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DY_DIAG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (stamp 5 = stores acknowledged; the shipped kernel ends with them in flight)
+#endif
   stamp(DY_ABLATE_OF(p), p.nblk, 5);
 }
 
@@ -580,32 +589,41 @@ __global__ __launch_bounds__(256, (BN == 64 && NBAND_ == 2) ? 3 : 2) void band_k
     b_cur = b_cur == DB * B_BYTES ? 0 : b_cur + B_BYTES;
     b_fill = b_fill == DB * B_BYTES ? 0 : b_fill + B_BYTES;
   };
-  for (int g = 0; g < ng; ++g) {
+  // With two bands (DB = 3) everything the LAST band group would issue is dead -- band ng and weight tiles nk .. nk + 2 -- and a dead
+  // DMA fetches nothing but still takes the full round trip to retire, which the wait in front of the epilogue (it reuses the ring) paid
+  // for once per tile.  The last group issues nothing and its waits shrink with what is no longer in flight: weight tiles t + 1, t + 2
+  // (tw = 0), t + 1 (tw = 1), nothing (tw = 2).
+  // (the last group is its own straight-line copy of the body: the same waits chosen by branches inside one loop body cost
+  //  band_kernel<128> 36 spilled registers)
+  auto group = [&](auto tailc) {
+    constexpr bool tail = decltype(tailc)::value;
     const unsigned tmc = th == 0 ? tm[0] : (th == 1 ? tm[1] : tm[2]);
     // ---- tw = 0: also refills the band slot the previous band group left
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue_band(band_fill);
-    issue_b(OFF_B + b_fill);
+    if constexpr (!tail) {
+      issue_band(band_fill);
+      issue_b(OFF_B + b_fill);
+    }
     __builtin_amdgcn_sched_barrier(0);
     compute(band_cur, OFF_B + b_cur, tmc, a_rd[0]);
     __builtin_amdgcn_sched_barrier(0);
     next_b();
     // ---- tw = 1
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(tail ? B_LD : N1) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue_b(OFF_B + b_fill);
+    if constexpr (!tail) issue_b(OFF_B + b_fill);
     __builtin_amdgcn_sched_barrier(0);
     compute(band_cur, OFF_B + b_cur, tmc >> 8, a_rd[1]);
     __builtin_amdgcn_sched_barrier(0);
     next_b();
     // ---- tw = 2
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(tail ? 0 : N1) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue_b(OFF_B + b_fill);
+    if constexpr (!tail) issue_b(OFF_B + b_fill);
     __builtin_amdgcn_sched_barrier(0);
     compute(band_cur, OFF_B + b_cur, tmc >> 16, a_rd[2]);
     __builtin_amdgcn_sched_barrier(0);
@@ -613,12 +631,17 @@ __global__ __launch_bounds__(256, (BN == 64 && NBAND_ == 2) ? 3 : 2) void band_k
     band_cur = band_cur == (NBAND - 1) * BAND_BYTES ? 0 : band_cur + BAND_BYTES;
     band_fill = band_fill == (NBAND - 1) * BAND_BYTES ? 0 : band_fill + BAND_BYTES;
     th = th == 2 ? 0 : th + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero fills beyond the last step have landed
+  };
+  constexpr bool peel = NBAND == 2;
+  for (int g = 0; g < ng - (peel ? 1 : 0); ++g) group(std::false_type{});
+  if (peel) group(std::true_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (three bands: the zero fills beyond the last step have landed)
   __builtin_amdgcn_s_barrier();
   stamp(DY_ABLATE_OF(p), p.nblk, 2);
   epilogue<BN, T, MB>(p, acc, smem, tid, lane, wave, wm, wn, m0, n0, tile_m);
+#ifdef DY_DIAG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   stamp(DY_ABLATE_OF(p), p.nblk, 5);
 }
 
