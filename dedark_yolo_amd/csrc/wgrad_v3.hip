@@ -11,7 +11,8 @@
 // The zero padding (one pixel left / right, zero rows above / below the image) is produced by the DMA itself (padding lanes
 // fetch a zero page), so there are no border masks anywhere.  Operands are read with ds_read_b64_tr_b16 (pixel-major LDS rows
 // -> 8 consecutive pixels of one channel per lane).  6 waves: wave w owns k' tiles 3w..3w+2 (of 18 = 9 taps x 2 ci tiles) x both
-// co tiles = 6 accumulator tiles; 10 transposing reads per 6 MFMA.  One barrier per image row.  With 128 input channels there are
+// co tiles = 6 accumulator tiles; 10 transposing reads per 6 MFMA, issued for the NEXT 16-pixel slice between the MFMAs of the current one
+// (two fragment sets); the row buffers are bank-swizzled (swizzle_key).  One barrier per image row.  With 128 input channels there are
 // 36 k' tiles on 12 waves; every block covers 64 output channels (blockIdx.y selects the 64-wide slice of dz).
 // Partial sums go to `scratch` as [co slice][block][9*CI][64] f32 and a second kernel adds them in a fixed order.
 #include <stdlib.h>
