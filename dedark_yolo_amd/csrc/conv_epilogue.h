@@ -102,6 +102,8 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
   constexpr int ITERS = BM / PPI / NW;
   constexpr int HALVES = BN >= 128 ? BN / 128 : 1;
   const int pl = lane / LPP, chunk = lane % LPP;
+  const bool nt = accumulate & 2;                   // bit 1 (set by the launcher): plain stores of an output beyond 128 MB go non-temporal
+  accumulate &= 1;
 #pragma unroll 2
   for (int u = 0; u < ITERS; ++u) {
     const int px = PPI * (wave + NW * u) + pl;
@@ -131,6 +133,10 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
               for (int e = 0; e < 8; ++e) y[e] += x[e];
             }
             stvec<T16>(o, y);
+          } else if (nt) {
+            // (as inline asm: with the builtin the two branches differ only in their !nontemporal metadata and SimplifyCFG sinks them into
+            //  ONE plain store)
+            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o), "v"(v) : "memory");
           } else {
             *reinterpret_cast<u32x4*>(o) = v;
           }

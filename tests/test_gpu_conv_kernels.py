@@ -112,6 +112,9 @@ ROUTED = [
     ((20, 128, 128, 57, 61, 3, 1, 2, 2), ("v5::conv_kernel<128>", "v5::conv_kernel<128>", None)),               # dilated, ragged
     ((20, 96, 224, 57, 61, 3, 1, 1), ("v5::band_kernel<128>", None, "wg4::wgrad_kernel")),                      # 96 = 3 x 32 source channels, ragged
     ((12, 64, 64, 160, 160, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", "wg3::wgrad_kernel<64>")),
+    # outputs beyond 128 MiB: the plain epilogue stores of conv_v4 / conv_v5 / the band kernel go non-temporal (conv_epilogue.h: store_rows)
+    ((42, 64, 64, 160, 160, 3, 1, 1), ("v5::band_kernel<64>", "v5::band_kernel<64>", "wg3::wgrad_kernel<64>")),
+    ((42, 256, 256, 80, 80, 3, 1, 1), ("v4::conv_kernel", "v4::conv_kernel", "wg4::wgrad_kernel")),
     ((44, 256, 64, 40, 40, 3, 1, 1), ("v5::band_kernel<64>", None, None)),                                      # Detect stem: 8 channel chunks
     ((8, 320, 128, 160, 160, 1, 1, 0), ("v5::conv_kernel<128>", None, None)),
     ((6, 64, 256, 63, 65, 5, 1, 2), (None, None, "wg4::wgrad_kernel")),                                         # 5x5 taps in the mixed-radix walk
