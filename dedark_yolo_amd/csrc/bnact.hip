@@ -10,6 +10,12 @@
 #include "dy_common.h"
 #include "../../include/dedark_yolo.h"
 
+// tensors beyond this many MiB are streamed with non-temporal loads / stores by the forward pass (tools/gpu: variant builds with
+// -DDY_BN_NT_FWD_MB=n)
+#ifndef DY_BN_NT_FWD_MB
+#define DY_BN_NT_FWD_MB 128
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -413,7 +419,7 @@ extern "C" int dy_bn_act_fwd(const void* z, int64_t z_ld, const float* scale, co
   const Geo g = geometry(pixels, C, ve, 0);
   const size_t shm = 2 * (size_t)g.cgb * ve * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > (128L << 20);
+  const bool big = pixels * C * (dtype == DY_F32 ? 4 : 2) > ((long)DY_BN_NT_FWD_MB << 20);
   dy_note_kernel("bn_act_fwd_kernel");
 #define FWD(T_, U_) bn_act_fwd_kernel<T_, U_, (U_ == 4)><<<g.grid, NT, shm, st>>>((const T_*)z, z_ld, scale, shift, act, (const T_*)residual, res_ld, \
                                                                     (T_*)y, y_ld, pixels, C, g.cgb, g.rows)
