@@ -132,7 +132,13 @@ __device__ inline void store_rows(const char* smem, int lane, int wave, long m0,
 #pragma unroll
               for (int e = 0; e < 8; ++e) y[e] += x[e];
             }
-            stvec<T16>(o, y);
+            if (nt) {
+              u32x4 w;
+              stvec<T16>(reinterpret_cast<T16*>(&w), y);
+              asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o), "v"(w) : "memory");
+            } else {
+              stvec<T16>(o, y);
+            }
           } else if (nt) {
             // (as inline asm: with the builtin the two branches differ only in their !nontemporal metadata and SimplifyCFG sinks them into
             //  ONE plain store)

@@ -603,7 +603,7 @@ static int v4_launch(const dy_conv_desc* d, int mode, void* stream, int force_va
   p.scale = d->scale; p.shift = d->shift; p.act = d->act; p.stats = d->stats; p.accumulate = d->accumulate;
   // (bit 1: an output beyond 128 MB is streamed past the L2 with non-temporal stores -- its lines would evict the operand lines the
   //  taps re-read, and whoever reads it next streams it from memory anyway)
-  if (!d->accumulate && !d->add_src && (long)d->N * d->Hd * d->Wd * d->Cd * 2 > (128L << 20)) p.accumulate |= 2;
+  if ((long)d->N * d->Hd * d->Wd * d->Cd * 2 > (128L << 20)) p.accumulate |= 2;
   p.M = (long)d->N * d->Hd * d->Wd;
   p.add_src = mode == 1 ? (const char*)d->add_src : nullptr; p.add_src_ld = d->add_src_ld;
   p.nk = d->KH * d->KW * d->Cs / v4::BK;

@@ -257,3 +257,40 @@ def test_px1x1_kernel(dtype, K, N, mode):
         s1, s2 = raw.double().sum((0, 2, 3)), (raw.double() ** 2).sum((0, 2, 3))
         assert float((t[0] - s1).abs().max()) <= 1e-4 * float(raw.abs().double().sum((0, 2, 3)).max())
         assert float((t[1] - s2).abs().max()) <= 1e-4 * float(s2.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "acc", "add"])
+def test_big_output_epilogue_non_temporal_stores(mode):
+    """An output beyond 128 MiB leaves the tiled kernels through non-temporal stores (conv_epilogue.h: store_rows, bit 1 of its
+    `accumulate` argument) -- also when the epilogue adds into the destination (fan-out data gradients, `accumulate`) or adds a second
+    view on the way out (`add_src`, the Bottleneck shortcut gradient).  1x1 512 -> 256 at 80x80, B = 42: 137.6 MB of output."""
+    import ctypes as C
+    from dedark_yolo_amd import _C, ops
+    from dedark_yolo_amd.ops import stream
+    dtype = torch.bfloat16
+    torch.manual_seed(5)
+    B, K, N, H, W = 42, 512, 256, 80, 80
+    assert B * H * W * N * 2 > (128 << 20)
+    x = torch.randn(B, K, H, W, device="cuda") * 0.5
+    w = torch.randn(N, K, 1, 1, device="cuda") * (1.0 / K ** 0.5)
+    xn = ops.as_nhwc(x, dtype)
+    wp = ops._pack(w, N, K, False, dtype)
+    y = ops.empty_nhwc(B, N, H, W, dtype, x.device)
+    old = torch.randn(B, N, H, W, device="cuda")
+    addend = ops.as_nhwc(torch.randn(B, N, H, W, device="cuda"), dtype)
+    if mode == "acc":
+        y.copy_(old.to(dtype))
+    d = ops._conv_desc(xn, wp, y, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, None, None, 0, None, mode == "acc", dtype)
+    if mode == "add":
+        d.add_src, d.add_src_ld = addend.data_ptr(), ops.ld_of(addend)
+    _C.lib().dy_clear_last_kernel()
+    _C.call("dy_conv2d_dgrad", C.byref(d), stream())
+    torch.cuda.synchronize()
+    assert _C.lib().dy_last_kernel().decode().startswith(("v4::conv_kernel", "v5::conv_kernel"))
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float())
+    if mode == "acc":
+        ref = ref + old.to(dtype).float()
+    if mode == "add":
+        ref = ref + addend.float()
+    assert _err(y.float(), ref) < 1e-2
