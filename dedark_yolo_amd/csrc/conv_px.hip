@@ -186,11 +186,20 @@ bool dy_conv_px_eligible(const dy_conv_desc* d) {
   return (long)d->N * d->Hd * d->Wd >= 262144;
 }
 
+// (the statistics variant keeps 2 x 8 x NS register sums: it exists for NS <= 4 only -- dy_conv_px_eligible admits BatchNorm sums up to 128
+//  output channels -- and the wider instantiations, 125-227 spilled registers each, are not built)
 template <int KB, int NS, typename T>
 static int px_go(const px::P& p, bool stats, size_t shm, unsigned blocks, hipStream_t st) {
+  constexpr bool HAS_STATS = NS <= 4;
   static bool configured_s = false, configured_p = false;
   bool& configured = stats ? configured_s : configured_p;
-  const void* fn = stats ? reinterpret_cast<const void*>(&px::px1x1_kernel<KB, NS, T, true>) : reinterpret_cast<const void*>(&px::px1x1_kernel<KB, NS, T, false>);
+  const void* fn = reinterpret_cast<const void*>(&px::px1x1_kernel<KB, NS, T, false>);
+  if constexpr (HAS_STATS) {
+    if (stats) fn = reinterpret_cast<const void*>(&px::px1x1_kernel<KB, NS, T, true>);
+  } else if (stats) {
+    dy_set_error("conv_px: no statistics variant for %d output channels per block", 32 * NS);
+    return 3;
+  }
   if (!configured) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
       dy_set_error("conv_px: hipFuncSetAttribute failed");
@@ -198,8 +207,13 @@ static int px_go(const px::P& p, bool stats, size_t shm, unsigned blocks, hipStr
     }
     configured = true;
   }
-  if (stats) px::px1x1_kernel<KB, NS, T, true><<<blocks, px::NT, shm, st>>>(p);
-  else px::px1x1_kernel<KB, NS, T, false><<<blocks, px::NT, shm, st>>>(p);
+  if constexpr (HAS_STATS) {
+    if (stats) {
+      px::px1x1_kernel<KB, NS, T, true><<<blocks, px::NT, shm, st>>>(p);
+      return 0;
+    }
+  }
+  px::px1x1_kernel<KB, NS, T, false><<<blocks, px::NT, shm, st>>>(p);
   return 0;
 }
 
